@@ -1,0 +1,220 @@
+/* mmqg.h — C ABI of the MI355X (gfx950) hot path of ksg14/multi-modal-qg.
+ *
+ * The reference is pure Python on PyTorch CPU ops and has no FFI of its own; the arithmetic
+ * this library replaces is the set of ATen calls made by model/decoder.py:74-107,
+ * model/encoder.py:58-71,95-100 and the step driver train.py:149-181.  Each entry point below
+ * names the reference lines it stands in for.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - the CALLER owns every buffer; pointers are raw device addresses (torch
+ *     tensor.data_ptr()), fp32 row-major unless stated, ids int64, lengths int32;
+ *   - the library never allocates, frees or synchronises; every function only enqueues
+ *     kernels (and memsets) on the hipStream_t passed as `stream`, so autograd ordering on
+ *     PyTorch's current stream holds and a call sequence can be captured into a hipGraph;
+ *   - return value 0 = enqueued, negative = error; mmqg_last_error() returns the
+ *     thread-local message (the Python side raises RuntimeError, as the reference's torch
+ *     calls would);
+ *   - gradient outputs named dw_* / db_* are ACCUMULATED into (+=), everything else is overwritten;
+ *   - attention segments are always stacked text | audio | video (widths Lt, Lav, Lav), the
+ *     order of the concat at decoder.py:99 and of the return tuple at decoder.py:107.
+ */
+#ifndef MMQG_H
+#define MMQG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMQG_ABI_VERSION 1
+#define MMQG_MAX_LAYERS 8
+
+typedef void* mmqg_stream; /* hipStream_t */
+
+enum { MMQG_K_MAJOR = 0, MMQG_MN_MAJOR = 1 };
+enum { MMQG_MASK_REFERENCE_NOOP = 0, MMQG_MASK_INTENDED = 1 };
+
+int mmqg_abi_version(void);
+const char* mmqg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM on the fp32 matrix cores.  C = (beta?C:0) + bias + bias2 + A*B [+ A2*B2].
+ * Replaces torch.nn.Linear / the gate matmuls inside nn.LSTM (decoder.py:64-70,78,84,92,104,106;
+ * encoder.py:54,91) and their autograd.  Layouts: MMQG_K_MAJOR = k contiguous (A[m*lda+k],
+ * B[n*ldb+k] i.e. a torch [out,in] weight used as x*W^T); MMQG_MN_MAJOR = m / n contiguous
+ * (A[k*lda+m], B[k*ldb+n]).  split_k: 1 = none, >1 = that many K slices combined with f32
+ * atomics, <0 = let the library choose. */
+int mmqg_gemm_f32(int a_layout, int b_layout, int M, int N, int K,
+                  const float* A, int lda, const float* B, int ldb,
+                  const float* A2, int lda2, const float* B2, int ldb2, int K2,
+                  const float* bias, const float* bias2, int beta, float* C, int ldc,
+                  int split_k, mmqg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding lookup and its dense gradient (nn.Embedding shared by encoder.py:96 and
+ * decoder.py:75; train.py:25-31).  ids outside [0,V) yield a zero row / are skipped. */
+int mmqg_embedding_fwd(const float* table, const int64_t* ids, float* out, int n, int V, int E,
+                       int ld_out, mmqg_stream stream);
+int mmqg_embedding_bwd(const float* dout, int ld_dout, const int64_t* ids, float* dtable, int n,
+                       int V, int E, mmqg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder attention (decoder.py:78-95).  The value tensors of one question are
+ * text [Lt][H], audio [Lav][Da], video [Lav][Dv]; *_stride_b is the element distance between
+ * consecutive questions, so three separate tensors and one fused (text|audio|video) allocation
+ * per question are both expressible.  text_len / av_len are read only when
+ * mask_mode == MMQG_MASK_INTENDED (the reference's masks at decoder.py:79,85,93 are no-ops). */
+typedef struct {
+    int32_t B, Lt, Lav, H, Da, Dv;
+    const float* text;  int64_t text_stride_b;
+    const float* audio; int64_t audio_stride_b;
+    const float* video; int64_t video_stride_b;
+    const int32_t* text_len;
+    const int32_t* av_len;
+    int32_t mask_mode;
+} mmqg_attn_values;
+
+/* scores [B][ld_s] (pre-softmax, Lt+2*Lav wide) -> attn [B][ld_a] (must NOT alias scores) and
+ * ctx [B][ld_c] = text ctx (H) | audio ctx (Da) | video ctx (Dv). */
+int mmqg_attn_softmax_context_fwd(const mmqg_attn_values* v, const float* scores, int ld_s,
+                                  float* attn, int ld_a, float* ctx, int ld_c, mmqg_stream stream);
+/* dscores[b] = softmax'(attn[b]) applied to d(attn) = values . dctx (+ dattn, the gradient of
+ * the returned attention weights themselves, nullable) */
+int mmqg_attn_context_bwd(const mmqg_attn_values* v, const float* attn, int ld_a,
+                          const float* dctx, int ld_c, const float* dattn, int ld_da,
+                          float* dscores, int ld_ds, mmqg_stream stream);
+/* gradient of the first n_rows value rows of one modality, summed over T steps:
+ * out[b][row][:] (+)= sum_t attn[t][b][seg_off+row] * dctx[t][b][ctx_off : ctx_off+D] */
+int mmqg_attn_dvalues(int T, int B, int n_rows, int D,
+                      const float* attn, int64_t attn_stride_t, int ld_a, int seg_off,
+                      const float* dctx, int64_t dctx_stride_t, int ld_c, int ctx_off,
+                      float* out, int64_t out_stride_row, int64_t out_stride_b, int accumulate,
+                      mmqg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LSTM cell (the pointwise part of nn.LSTM, gate order i,f,g,o).  gates [B][4H] holds the
+ * summed pre-activations on entry and the activated gates on exit (kept for backward).
+ * lens/t: row b is updated only while t < lens[b] (ragged batches), otherwise its state is
+ * carried.  h_drop (nullable) receives h_out times the inter-layer dropout scale, a pure
+ * function of (seed, stream_id, b*H+j) — see mmqg_dropout_mask. */
+int mmqg_lstm_cell_fwd(int B, int H, float* gates, int ld_g, const float* h_prev, const float* c_prev,
+                       float* h_out, float* c_out, float* h_drop, float* y_out, int64_t y_stride_b,
+                       const int32_t* lens, int t, float dropout_p, uint64_t seed, uint64_t stream_id,
+                       mmqg_stream stream);
+int mmqg_lstm_cell_bwd(int B, int H, const float* gates_act, const float* c_prev, const float* c_new,
+                       float* dh_rec, const float* dh_above, int64_t above_stride_b, float dropout_p,
+                       uint64_t seed, uint64_t stream_id, const float* dh_extra, int64_t extra_stride_b,
+                       float* dc, float* dgates, int ld_dg, const int32_t* lens, int t,
+                       mmqg_stream stream);
+/* out[i] = 0 or 1/(1-p): the scale the kernels apply to element i of stream `stream_id`.
+ * seed_offset (nullable, also a field of the sequence descriptors): a device int32 that is
+ * mixed into the seed when the kernel RUNS, so a captured graph that is replayed with the
+ * step counter advanced draws fresh masks. */
+int mmqg_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id,
+                      const int32_t* seed_offset, mmqg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cross entropy over vocabulary logits (train.py:174,264) with the argmax used by the greedy
+ * decode (train.py:107-108).  loss_rows[r] = row_weight[r] * CE(logits[r], target[r]);
+ * dlogits (nullable, may alias logits) = row_weight[r] * (softmax - onehot). */
+int mmqg_ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* row_weight,
+                    int rows, int V, float* loss_rows, int64_t* argmax, float* dlogits, int ld_d,
+                    mmqg_stream stream);
+int mmqg_colsum_add(const float* X, int ld, int M, int N, float* out, mmqg_stream stream);
+int mmqg_reduce_sum(const float* x, int n, float* out, mmqg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam (torch.optim.Adam defaults, train.py:265-267,179-181) over a flat parameter range.
+ * `step` is a device int32 holding the 1-based step number (so a captured graph can be
+ * replayed); grads are multiplied by grad_scale first (1/world_size after an all-reduce sum). */
+int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                   float b2, float eps, const int32_t* step, float grad_scale, mmqg_stream stream);
+int mmqg_counter_add(int32_t* counter, int delta, mmqg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-sequence executors: one call enqueues every kernel of a time loop.
+ *
+ * mmqg_lstm_seq: stacked LSTM over T steps, time-major, zero or given initial state.  Serves
+ * TextEncoder driven by train.py:159-166 (L=3, input = embedded context tokens) and the LSTM
+ * stage of VideoConvLstmEncoder (encoder.py:54,69; L=1).  Layer by layer: the input product
+ * X*W_ih^T of a whole layer is one GEMM, only h*W_hh^T + cell stay in the time loop. */
+typedef struct {
+    int32_t T, B, L, H, In;
+    const float* x; int32_t ldx;                    /* [T][B][In] */
+    const float* w_ih[MMQG_MAX_LAYERS];             /* [4H][In or H] */
+    const float* w_hh[MMQG_MAX_LAYERS];             /* [4H][H] */
+    const float* b_ih[MMQG_MAX_LAYERS];
+    const float* b_hh[MMQG_MAX_LAYERS];
+    const float* h0; const float* c0;               /* [L][B][H] or NULL = zeros */
+    const int32_t* lens;                            /* [B] or NULL */
+    float dropout_p; int32_t training; uint64_t seed; uint64_t stream_base;
+    const int32_t* seed_offset;                     /* nullable, see mmqg_dropout_mask */
+    float* gates;                                   /* [L][T][B][4H] */
+    float* hs; float* cs;                           /* [L][T+1][B][H]; slot 0 = initial state */
+    float* hdrop;                                   /* [L-1][T][B][H], NULL if no dropout */
+    float* y; int64_t y_stride_t; int64_t y_stride_b; /* optional top-layer outputs (0 past lens) */
+} mmqg_lstm_seq;
+
+typedef struct {
+    const float* dy; int64_t dy_stride_t; int64_t dy_stride_b; /* grad of y, nullable */
+    const float* dhT; const float* dcT;             /* [L][B][H] grad of the final state, nullable */
+    float* dgates;                                  /* [L][T][B][4H] scratch */
+    float* dxl;                                     /* [T][B][H] scratch */
+    float* dh; float* dc;                           /* [B][H] scratch */
+    float* dx; int32_t lddx;                        /* [T][B][In] out, nullable */
+    float* dw_ih[MMQG_MAX_LAYERS]; float* dw_hh[MMQG_MAX_LAYERS];
+    float* db_ih[MMQG_MAX_LAYERS]; float* db_hh[MMQG_MAX_LAYERS];
+    float* dh0; float* dc0;                         /* [L][B][H] out, nullable */
+} mmqg_lstm_seq_grad;
+
+int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream);
+int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_stream stream);
+
+/* mmqg_decoder_seq: AttnDecoder.forward (decoder.py:74-107) for T teacher-forced steps
+ * (train.py:171-175): per step attention scores, three softmaxes, three contexts, the L-layer
+ * LSTM step.  Products that do not depend on the recurrence (the embedded-word part of the
+ * scores and of the layer-0 gates) are hoisted into two GEMMs over all T*B rows; the vocabulary
+ * projection (decoder.py:106) runs afterwards as one GEMM over hs[L-1][1..T]. */
+typedef struct {
+    int32_t T, B, L, H, E;
+    mmqg_attn_values values;
+    const float* xemb;                              /* [T][B][E] embedded input words */
+    const float* w_attn; const float* b_attn;       /* [Lt+2Lav][E+H], [Lt+2Lav] */
+    const float* w_ih[MMQG_MAX_LAYERS]; const float* w_hh[MMQG_MAX_LAYERS];
+    const float* b_ih[MMQG_MAX_LAYERS]; const float* b_hh[MMQG_MAX_LAYERS];
+    const float* h0; const float* c0;               /* [L][B][H] */
+    const int32_t* lens;                            /* [B] target lengths or NULL */
+    float dropout_p; int32_t training; uint64_t seed; uint64_t stream_base;
+    const int32_t* seed_offset;
+    float* scores;                                  /* [T][B][ld_attn] scratch: pre-softmax scores */
+    float* attn; int32_t ld_attn;                   /* [T][B][ld_attn] attention weights (kept for backward) */
+    float* ctx;                                     /* [T][B][H+Da+Dv] */
+    float* gates;                                   /* [L][T][B][4H] */
+    float* hs; float* cs;                           /* [L][T+1][B][H] */
+    float* hdrop;                                   /* [L-1][T][B][H] or NULL */
+} mmqg_decoder_seq;
+
+typedef struct {
+    const float* dhtop;                             /* [T][B][H] grad of hs[L-1][1..T] */
+    float* dgates;                                  /* [L][T][B][4H] */
+    float* dscores; int32_t ld_ds;                  /* [T][B][ld_ds] */
+    float* dctx;                                    /* [T][B][H+Da+Dv] */
+    float* dh; float* dc;                           /* [L][B][H] scratch; on exit grad of h0/c0 */
+    float* dxa;                                     /* [L][B][H] scratch */
+    float* dxemb;                                   /* [T][B][E] out */
+    float* dw_attn; float* db_attn;
+    float* dw_ih[MMQG_MAX_LAYERS]; float* dw_hh[MMQG_MAX_LAYERS];
+    float* db_ih[MMQG_MAX_LAYERS]; float* db_hh[MMQG_MAX_LAYERS];
+    /* gradient of the leading value rows (the only ones an encoder produced) */
+    int32_t n_text_rows;  float* dtext;  int64_t dtext_stride_row;  int64_t dtext_stride_b;
+    int32_t n_video_rows; float* dvideo; int64_t dvideo_stride_row; int64_t dvideo_stride_b;
+} mmqg_decoder_seq_grad;
+
+int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream);
+int mmqg_decoder_seq_bwd(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g, mmqg_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMQG_H */

@@ -1,0 +1,143 @@
+"""ctypes binding of ``libmmqg_hip.so`` (the C ABI declared in ``include/mmqg.h``).
+
+The library is the product path: if it cannot be loaded, or a call is attempted with
+tensors that are not on a ROCm device, this module raises — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmmqg_hip.so")
+ABI_VERSION = 1
+MAX_LAYERS = 8
+
+K_MAJOR, MN_MAJOR = 0, 1
+MASK_REFERENCE_NOOP, MASK_INTENDED = 0, 1
+
+c_f = C.c_void_p          # device pointers travel as void* (tensor.data_ptr())
+c_i = C.c_int
+c_i64 = C.c_int64
+c_u64 = C.c_uint64
+c_fl = C.c_float
+
+
+class AttnValues(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Lt", C.c_int32), ("Lav", C.c_int32), ("H", C.c_int32), ("Da", C.c_int32),
+                ("Dv", C.c_int32),
+                ("text", c_f), ("text_stride_b", c_i64),
+                ("audio", c_f), ("audio_stride_b", c_i64),
+                ("video", c_f), ("video_stride_b", c_i64),
+                ("text_len", c_f), ("av_len", c_f), ("mask_mode", C.c_int32)]
+
+
+_PTRS = c_f * MAX_LAYERS
+
+
+class LstmSeq(C.Structure):
+    _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("In", C.c_int32),
+                ("x", c_f), ("ldx", C.c_int32),
+                ("w_ih", _PTRS), ("w_hh", _PTRS), ("b_ih", _PTRS), ("b_hh", _PTRS),
+                ("h0", c_f), ("c0", c_f), ("lens", c_f),
+                ("dropout_p", c_fl), ("training", C.c_int32), ("seed", c_u64), ("stream_base", c_u64),
+                ("seed_offset", c_f),
+                ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f),
+                ("y", c_f), ("y_stride_t", c_i64), ("y_stride_b", c_i64)]
+
+
+class LstmSeqGrad(C.Structure):
+    _fields_ = [("dy", c_f), ("dy_stride_t", c_i64), ("dy_stride_b", c_i64),
+                ("dhT", c_f), ("dcT", c_f),
+                ("dgates", c_f), ("dxl", c_f), ("dh", c_f), ("dc", c_f),
+                ("dx", c_f), ("lddx", C.c_int32),
+                ("dw_ih", _PTRS), ("dw_hh", _PTRS), ("db_ih", _PTRS), ("db_hh", _PTRS),
+                ("dh0", c_f), ("dc0", c_f)]
+
+
+class DecoderSeq(C.Structure):
+    _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("E", C.c_int32),
+                ("values", AttnValues),
+                ("xemb", c_f), ("w_attn", c_f), ("b_attn", c_f),
+                ("w_ih", _PTRS), ("w_hh", _PTRS), ("b_ih", _PTRS), ("b_hh", _PTRS),
+                ("h0", c_f), ("c0", c_f), ("lens", c_f),
+                ("dropout_p", c_fl), ("training", C.c_int32), ("seed", c_u64), ("stream_base", c_u64),
+                ("seed_offset", c_f),
+                ("scores", c_f), ("attn", c_f), ("ld_attn", C.c_int32),
+                ("ctx", c_f), ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f)]
+
+
+class DecoderSeqGrad(C.Structure):
+    _fields_ = [("dhtop", c_f), ("dgates", c_f), ("dscores", c_f), ("ld_ds", C.c_int32),
+                ("dctx", c_f), ("dh", c_f), ("dc", c_f), ("dxa", c_f), ("dxemb", c_f),
+                ("dw_attn", c_f), ("db_attn", c_f),
+                ("dw_ih", _PTRS), ("dw_hh", _PTRS), ("db_ih", _PTRS), ("db_hh", _PTRS),
+                ("n_text_rows", C.c_int32), ("dtext", c_f), ("dtext_stride_row", c_i64), ("dtext_stride_b", c_i64),
+                ("n_video_rows", C.c_int32), ("dvideo", c_f), ("dvideo_stride_row", c_i64), ("dvideo_stride_b", c_i64)]
+
+
+# name -> argtypes (return type is int unless noted); kept in one table so the CPU test can
+# check that the shared object exports every symbol the header declares.
+SIGNATURES = {
+    "mmqg_abi_version": [],
+    "mmqg_last_error": [],
+    "mmqg_gemm_f32": [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_i,
+                      c_i, c_f],
+    "mmqg_embedding_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    "mmqg_embedding_bwd": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f],
+    "mmqg_attn_softmax_context_fwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f],
+    "mmqg_attn_context_bwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f],
+    "mmqg_attn_dvalues": [c_i, c_i, c_i, c_i, c_f, c_i64, c_i, c_i, c_f, c_i64, c_i, c_i, c_f, c_i64, c_i64, c_i, c_f],
+    "mmqg_lstm_cell_fwd": [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_i, c_fl, c_u64, c_u64, c_f],
+    "mmqg_lstm_cell_bwd": [c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i64, c_fl, c_u64, c_u64, c_f, c_i64, c_f, c_f, c_i,
+                           c_f, c_i, c_f],
+    "mmqg_dropout_mask": [c_f, c_i64, c_fl, c_u64, c_u64, c_f, c_f],
+    "mmqg_ce_fwd_bwd": [c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i, c_f],
+    "mmqg_colsum_add": [c_f, c_i, c_i, c_i, c_f, c_f],
+    "mmqg_reduce_sum": [c_f, c_i, c_f, c_f],
+    "mmqg_adam_step": [c_f, c_f, c_f, c_f, c_i64, c_fl, c_fl, c_fl, c_fl, c_f, c_fl, c_f],
+    "mmqg_counter_add": [c_f, c_i, c_f],
+    "mmqg_lstm_seq_fwd": [C.POINTER(LstmSeq), c_f],
+    "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
+    "mmqg_decoder_seq_fwd": [C.POINTER(DecoderSeq), c_f],
+    "mmqg_decoder_seq_bwd": [C.POINTER(DecoderSeq), C.POINTER(DecoderSeqGrad), c_f],
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class BackendError(RuntimeError):
+    """The HIP extension is missing or a kernel launch was rejected."""
+
+
+def load() -> C.CDLL:
+    """Load the shared object once, bind the signatures and check the ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(
+            f"mmqg: HIP extension not built ({LIB_PATH} missing). Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C multi-modal-qg_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "mmqg_last_error" else C.c_int
+    got = lib.mmqg_abi_version()
+    if got != ABI_VERSION:
+        raise BackendError(f"mmqg: ABI mismatch: library {got}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mmqg_last_error()
+        raise BackendError(f"mmqg {what}: {msg.decode() if msg else 'error'} (rc={rc})")
+
+
+def ptr(t) -> Optional[int]:
+    """Device address of a tensor, or None."""
+    return None if t is None else t.data_ptr()

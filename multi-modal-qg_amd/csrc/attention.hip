@@ -1,0 +1,372 @@
+// Decoder attention for one time step (model/decoder.py:78-95): three location-style
+// attentions (text / audio / video) whose scores have already been produced by the score
+// GEMM.  This file holds the HBM-bound part:
+//
+//   fwd  : per (question, modality): softmax over the score segment, then
+//          ctx[:] = sum_i w[i] * V[i][:]  — a weighted row sum that streams the question's
+//          value rows exactly once.  0.5 FLOP per byte -> bounded by HBM bandwidth.
+//   bwd  : d(attn)[i] = V[i][:] . dctx[:]  (streams the rows once more), then the softmax
+//          Jacobian; the value gradient is NOT accumulated step by step: attn_dvalues forms
+//          it once after the time loop as sum_t attn[t] (x) dctx[t], and only for the rows an
+//          encoder actually produced.
+//
+// Work split.  The value tensor of a batch is B x (Lt*H + Lav*Da + Lav*Dv) floats
+// (838,144 B per question at the config.py extents).  Forward: one workgroup per
+// (question, modality, 128-column chunk); the 256 threads are 32 column lanes (float4 each,
+// 512 contiguous bytes per row) x 8 row groups, every thread keeps 4 independent 16-byte
+// loads in flight; the softmax weights of the segment live in LDS (the reductions are
+// wavefront shuffles + one 4-entry LDS exchange), the 8 row-group partials are combined
+// through LDS.  Backward: one workgroup per (question, modality, 32-row block), one
+// wavefront per row at a time, lanes across the row's columns (whole contiguous rows),
+// shuffle reduction per row.
+#include <algorithm>
+
+#include "mmqg_common.h"
+#include "mmqg_kernels.h"
+
+namespace {
+
+constexpr int kChunk = 128;      // value columns per forward workgroup
+constexpr int kMaxRows = 4096;   // longest score segment the LDS weight buffer holds
+constexpr int kRowBlock = 32;    // value rows per backward workgroup
+
+struct Segment {
+    const float* base;   // value rows of question b for this modality
+    int L, D;            // rows, columns
+    int seg_off;         // offset of the segment inside a score row
+    int ctx_off;         // offset inside a context row
+    int valid;           // rows that count under MMQG_MASK_INTENDED
+};
+
+__device__ __forceinline__ Segment pick_segment(const mmqg_attn_values& v, int modality, int b) {
+    Segment s;
+    if (modality == 0) {
+        s.base = v.text + (int64_t)b * v.text_stride_b; s.L = v.Lt; s.D = v.H; s.seg_off = 0; s.ctx_off = 0;
+        s.valid = v.text_len ? v.text_len[b] : v.Lt;
+    } else if (modality == 1) {
+        s.base = v.audio + (int64_t)b * v.audio_stride_b; s.L = v.Lav; s.D = v.Da; s.seg_off = v.Lt; s.ctx_off = v.H;
+        s.valid = v.av_len ? v.av_len[b] : v.Lav;
+    } else {
+        s.base = v.video + (int64_t)b * v.video_stride_b; s.L = v.Lav; s.D = v.Dv; s.seg_off = v.Lt + v.Lav;
+        s.ctx_off = v.H + v.Da;
+        s.valid = v.av_len ? v.av_len[b] : v.Lav;
+    }
+    return s;
+}
+
+__device__ __forceinline__ float block_max(float x, float* sh) {
+    x = wave_max(x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sh[wave] = x;
+    __syncthreads();
+    float r = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, sh[w]);
+    return r;
+}
+__device__ __forceinline__ float block_sum(float x, float* sh) {
+    x = wave_sum(x);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sh[wave] = x;
+    __syncthreads();
+    float r = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += sh[w];
+    return r;
+}
+
+struct AttnFwdK {
+    mmqg_attn_values v;
+    const float* scores; int ld_s;
+    float* attn; int ld_a;
+    float* ctx; int ld_c;
+    int chunks_text, chunks_audio;   // chunk index boundaries (video chunks follow)
+    int vec_text, vec_audio, vec_video;
+};
+
+__global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK a) {
+    __shared__ float w[kMaxRows];
+    __shared__ __attribute__((aligned(16))) float red[8 * kChunk];
+    __shared__ float sh[4];
+
+    const int b = blockIdx.y;
+    int chunk = blockIdx.x, modality = 0;
+    if (chunk >= a.chunks_text) { chunk -= a.chunks_text; modality = 1; }
+    if (modality == 1 && chunk >= a.chunks_audio) { chunk -= a.chunks_audio; modality = 2; }
+    const Segment sg = pick_segment(a.v, modality, b);
+    const bool vec = modality == 0 ? a.vec_text : (modality == 1 ? a.vec_audio : a.vec_video);
+    const int tid = threadIdx.x;
+    const bool masked = a.v.mask_mode == MMQG_MASK_INTENDED;
+
+    // ---- softmax of the score segment (every chunk of the segment recomputes it; L <= a few hundred)
+    const float* srow = a.scores + (int64_t)b * a.ld_s + sg.seg_off;
+    float lmax = -INFINITY;
+    for (int i = tid; i < sg.L; i += 256) {
+        float s = srow[i];
+        if (masked && i >= sg.valid) s = -INFINITY;
+        w[i] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    const float m = block_max(lmax, sh);
+    float lsum = 0.f;
+    for (int i = tid; i < sg.L; i += 256) {
+        const float e = expf(w[i] - m);
+        w[i] = e;
+        lsum += e;
+    }
+    const float inv = 1.0f / block_sum(lsum, sh);
+    float* arow = a.attn + (int64_t)b * a.ld_a + sg.seg_off;
+    for (int i = tid; i < sg.L; i += 256) {
+        const float p = w[i] * inv;
+        w[i] = p;
+        if (chunk == 0) arow[i] = p;
+    }
+    __syncthreads();
+
+    // ---- weighted row sum over this workgroup's 128 columns
+    const int cl = tid & 31, rg = tid >> 5;
+    const int col = chunk * kChunk + 4 * cl;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    if (col < sg.D) {
+        const float* V = sg.base + col;
+        if (vec) {
+            int i = rg;
+            for (; i + 24 < sg.L; i += 32) {
+                const float4 x0 = *reinterpret_cast<const float4*>(V + (int64_t)(i) * sg.D);
+                const float4 x1 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 8) * sg.D);
+                const float4 x2 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 16) * sg.D);
+                const float4 x3 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 24) * sg.D);
+                const float w0 = w[i], w1 = w[i + 8], w2 = w[i + 16], w3 = w[i + 24];
+                acc0.x += w0 * x0.x; acc0.y += w0 * x0.y; acc0.z += w0 * x0.z; acc0.w += w0 * x0.w;
+                acc1.x += w1 * x1.x; acc1.y += w1 * x1.y; acc1.z += w1 * x1.z; acc1.w += w1 * x1.w;
+                acc0.x += w2 * x2.x; acc0.y += w2 * x2.y; acc0.z += w2 * x2.z; acc0.w += w2 * x2.w;
+                acc1.x += w3 * x3.x; acc1.y += w3 * x3.y; acc1.z += w3 * x3.z; acc1.w += w3 * x3.w;
+            }
+            for (; i < sg.L; i += 8) {
+                const float4 x0 = *reinterpret_cast<const float4*>(V + (int64_t)i * sg.D);
+                const float w0 = w[i];
+                acc0.x += w0 * x0.x; acc0.y += w0 * x0.y; acc0.z += w0 * x0.z; acc0.w += w0 * x0.w;
+            }
+        } else {
+            for (int i = rg; i < sg.L; i += 8) {
+                const float* r = V + (int64_t)i * sg.D;
+                const float w0 = w[i];
+                acc0.x += w0 * r[0];
+                if (col + 1 < sg.D) acc0.y += w0 * r[1];
+                if (col + 2 < sg.D) acc0.z += w0 * r[2];
+                if (col + 3 < sg.D) acc0.w += w0 * r[3];
+            }
+        }
+    }
+    acc0.x += acc1.x; acc0.y += acc1.y; acc0.z += acc1.z; acc0.w += acc1.w;
+    *reinterpret_cast<float4*>(&red[rg * kChunk + 4 * cl]) = acc0;
+    __syncthreads();
+    if (tid < kChunk) {
+        const int c = chunk * kChunk + tid;
+        if (c < sg.D) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += red[r * kChunk + tid];
+            a.ctx[(int64_t)b * a.ld_c + sg.ctx_off + c] = s;
+        }
+    }
+}
+
+struct AttnBwdK {
+    mmqg_attn_values v;
+    const float* dctx; int ld_c;
+    float* dscores; int ld_ds;
+    int blocks_text, blocks_audio;
+    int vec_text, vec_audio, vec_video;
+};
+
+// d(attn)[b][seg+i] = V[b][i][:] . dctx[b][ctx_off : ctx_off + D]
+__global__ __launch_bounds__(256) void attn_dweights_kernel(AttnBwdK a) {
+    const int b = blockIdx.y;
+    int blk = blockIdx.x, modality = 0;
+    if (blk >= a.blocks_text) { blk -= a.blocks_text; modality = 1; }
+    if (modality == 1 && blk >= a.blocks_audio) { blk -= a.blocks_audio; modality = 2; }
+    const Segment sg = pick_segment(a.v, modality, b);
+    const bool vec = modality == 0 ? a.vec_text : (modality == 1 ? a.vec_audio : a.vec_video);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* g = a.dctx + (int64_t)b * a.ld_c + sg.ctx_off;
+    float* out = a.dscores + (int64_t)b * a.ld_ds + sg.seg_off;
+    const int row_end = min(sg.L, (blk + 1) * kRowBlock);
+    for (int i = blk * kRowBlock + wave; i < row_end; i += 4) {
+        const float* r = sg.base + (int64_t)i * sg.D;
+        float acc = 0.f;
+        if (vec) {
+            for (int c = 4 * lane; c < sg.D; c += 256) {
+                const float4 x = *reinterpret_cast<const float4*>(r + c);
+                const float4 y = *reinterpret_cast<const float4*>(g + c);
+                acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+            }
+        } else {
+            for (int c = lane; c < sg.D; c += 64) acc += r[c] * g[c];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[i] = acc;
+    }
+}
+
+// in place: ds[i] = a[i] * (da[i] - sum_j a[j] da[j]) per (question, segment)
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(mmqg_attn_values v, const float* attn, int ld_a,
+                                                               float* dscores, int ld_ds, const float* dattn,
+                                                               int ld_da) {
+    __shared__ float sh[4];
+    const int b = blockIdx.y, modality = blockIdx.x;
+    const int L = modality == 0 ? v.Lt : v.Lav;
+    const int off = modality == 0 ? 0 : (modality == 1 ? v.Lt : v.Lt + v.Lav);
+    const float* ar = attn + (int64_t)b * ld_a + off;
+    float* dr = dscores + (int64_t)b * ld_ds + off;
+    const float* er = dattn ? dattn + (int64_t)b * ld_da + off : nullptr;   // gradient of the returned weights
+    float part = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) {
+        const float da = dr[i] + (er ? er[i] : 0.f);
+        dr[i] = da;
+        part += ar[i] * da;
+    }
+    const float dot = block_sum(part, sh);
+    for (int i = threadIdx.x; i < L; i += 256) dr[i] = ar[i] * (dr[i] - dot);
+}
+
+struct DValK {
+    int T, B, n_rows, D;
+    const float* attn; int64_t attn_stride_t; int ld_a; int seg_off;
+    const float* dctx; int64_t dctx_stride_t; int ld_c; int ctx_off;
+    float* out; int64_t out_stride_row; int64_t out_stride_b;
+    int accumulate;
+};
+constexpr int kDvRows = 8;
+constexpr int kDvMaxT = 256;
+
+template <int W>   // W = 4: float4 columns, W = 1: scalar columns
+__global__ __launch_bounds__(256) void attn_dvalues_kernel(DValK a) {
+    __shared__ float aw[kDvMaxT * kDvRows];
+    const int b = blockIdx.y, row0 = blockIdx.x * kDvRows;
+    for (int e = threadIdx.x; e < a.T * kDvRows; e += blockDim.x) {
+        const int t = e / kDvRows, r = e % kDvRows;
+        const int row = row0 + r;
+        aw[e] = row < a.n_rows ? a.attn[t * a.attn_stride_t + (int64_t)b * a.ld_a + a.seg_off + row] : 0.f;
+    }
+    __syncthreads();
+    const int ncol = a.D / W;
+    for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
+        float acc[kDvRows][W];
+#pragma unroll
+        for (int r = 0; r < kDvRows; ++r)
+#pragma unroll
+            for (int k = 0; k < W; ++k) acc[r][k] = 0.f;
+        for (int t = 0; t < a.T; ++t) {
+            const float* src = a.dctx + t * a.dctx_stride_t + (int64_t)b * a.ld_c + a.ctx_off + c * W;
+            float x[W];
+            if constexpr (W == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(src);
+                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+            } else {
+                x[0] = src[0];
+            }
+#pragma unroll
+            for (int r = 0; r < kDvRows; ++r) {
+                const float wv = aw[t * kDvRows + r];
+#pragma unroll
+                for (int k = 0; k < W; ++k) acc[r][k] += wv * x[k];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kDvRows; ++r) {
+            const int row = row0 + r;
+            if (row >= a.n_rows) continue;
+            float* dst = a.out + (int64_t)b * a.out_stride_b + (int64_t)row * a.out_stride_row + c * W;
+#pragma unroll
+            for (int k = 0; k < W; ++k) dst[k] = a.accumulate ? dst[k] + acc[r][k] : acc[r][k];
+        }
+    }
+}
+
+inline bool vec_ok(const float* p, int64_t stride_b, int D) {
+    return mmqg::aligned16(p) && (stride_b % 4 == 0) && (D % 4 == 0);
+}
+
+int check_values(const mmqg_attn_values& v, const char* who) {
+    MMQG_REQUIRE(v.B >= 0 && v.Lt > 0 && v.Lav > 0 && v.H > 0 && v.Da > 0 && v.Dv > 0, "%s: bad attention shape", who);
+    MMQG_REQUIRE(v.text && v.audio && v.video, "%s: null value tensor", who);
+    MMQG_REQUIRE(v.Lt <= kMaxRows && v.Lav <= kMaxRows, "%s: segment longer than %d rows", who, kMaxRows);
+    MMQG_REQUIRE(v.mask_mode == MMQG_MASK_REFERENCE_NOOP || v.mask_mode == MMQG_MASK_INTENDED, "%s: bad mask_mode", who);
+    MMQG_REQUIRE(v.mask_mode == MMQG_MASK_REFERENCE_NOOP || (v.text_len && v.av_len),
+                 "%s: MMQG_MASK_INTENDED needs text_len and av_len", who);
+    return 0;
+}
+
+}  // namespace
+
+namespace mmqg {
+
+int attn_softmax_context_fwd(const mmqg_attn_values& v, const float* scores, int ld_s, float* attn, int ld_a,
+                             float* ctx, int ld_c, hipStream_t s) {
+    MMQG_TRY(check_values(v, "attn_softmax_context_fwd"));
+    if (v.B == 0) return 0;
+    const int S = v.Lt + 2 * v.Lav;
+    MMQG_REQUIRE(scores && attn && ctx, "attn_softmax_context_fwd: null pointer");
+    MMQG_REQUIRE(scores != attn, "attn_softmax_context_fwd: attn must not alias scores");
+    MMQG_REQUIRE(ld_s >= S && ld_a >= S && ld_c >= v.H + v.Da + v.Dv, "attn_softmax_context_fwd: leading dimension too small");
+    AttnFwdK k;
+    k.v = v; k.scores = scores; k.ld_s = ld_s; k.attn = attn; k.ld_a = ld_a; k.ctx = ctx; k.ld_c = ld_c;
+    k.chunks_text = ceil_div(v.H, kChunk);
+    k.chunks_audio = ceil_div(v.Da, kChunk);
+    const int chunks_video = ceil_div(v.Dv, kChunk);
+    k.vec_text = vec_ok(v.text, v.text_stride_b, v.H);
+    k.vec_audio = vec_ok(v.audio, v.audio_stride_b, v.Da);
+    k.vec_video = vec_ok(v.video, v.video_stride_b, v.Dv);
+    dim3 grid(k.chunks_text + k.chunks_audio + chunks_video, v.B);
+    hipLaunchKernelGGL(attn_softmax_context_fwd_kernel, grid, dim3(256), 0, s, k);
+    return check_launch("attn_softmax_context_fwd");
+}
+
+int attn_context_bwd(const mmqg_attn_values& v, const float* attn, int ld_a, const float* dctx, int ld_c,
+                     const float* dattn, int ld_da, float* dscores, int ld_ds, hipStream_t s) {
+    MMQG_TRY(check_values(v, "attn_context_bwd"));
+    if (v.B == 0) return 0;
+    const int S = v.Lt + 2 * v.Lav;
+    MMQG_REQUIRE(attn && dctx && dscores, "attn_context_bwd: null pointer");
+    MMQG_REQUIRE(ld_a >= S && ld_ds >= S && ld_c >= v.H + v.Da + v.Dv, "attn_context_bwd: leading dimension too small");
+    MMQG_REQUIRE(!dattn || ld_da >= S, "attn_context_bwd: ld_da too small");
+    AttnBwdK k;
+    k.v = v; k.dctx = dctx; k.ld_c = ld_c; k.dscores = dscores; k.ld_ds = ld_ds;
+    k.blocks_text = ceil_div(v.Lt, kRowBlock);
+    k.blocks_audio = ceil_div(v.Lav, kRowBlock);
+    const int blocks_video = ceil_div(v.Lav, kRowBlock);
+    const bool g_ok = aligned16(dctx) && (ld_c % 4 == 0) && (v.H % 4 == 0) && (v.Da % 4 == 0);
+    k.vec_text = g_ok && vec_ok(v.text, v.text_stride_b, v.H);
+    k.vec_audio = g_ok && vec_ok(v.audio, v.audio_stride_b, v.Da);
+    k.vec_video = g_ok && vec_ok(v.video, v.video_stride_b, v.Dv);
+    dim3 grid(k.blocks_text + k.blocks_audio + blocks_video, v.B);
+    hipLaunchKernelGGL(attn_dweights_kernel, grid, dim3(256), 0, s, k);
+    MMQG_TRY(check_launch("attn_dweights"));
+    hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3(3, v.B), dim3(256), 0, s, v, attn, ld_a, dscores, ld_ds, dattn, ld_da);
+    return check_launch("attn_softmax_bwd");
+}
+
+int attn_dvalues(int T, int B, int n_rows, int D, const float* attn, int64_t attn_stride_t, int ld_a, int seg_off,
+                 const float* dctx, int64_t dctx_stride_t, int ld_c, int ctx_off, float* out, int64_t out_stride_row,
+                 int64_t out_stride_b, int accumulate, hipStream_t s) {
+    MMQG_REQUIRE(T >= 0 && B >= 0 && n_rows >= 0 && D > 0, "attn_dvalues: bad shape");
+    if (B == 0 || n_rows == 0) return 0;
+    MMQG_REQUIRE(T <= kDvMaxT, "attn_dvalues: more than %d steps", kDvMaxT);
+    MMQG_REQUIRE(attn && dctx && out, "attn_dvalues: null pointer");
+    DValK k{T, B, n_rows, D, attn, attn_stride_t, ld_a, seg_off, dctx, dctx_stride_t, ld_c, ctx_off,
+            out, out_stride_row, out_stride_b, accumulate};
+    dim3 grid(ceil_div(n_rows, kDvRows), B);
+    const bool vec = (D % 4 == 0) && aligned16(dctx) && (ld_c % 4 == 0) && (ctx_off % 4 == 0) &&
+                     (dctx_stride_t % 4 == 0) && aligned16(out) && (out_stride_row % 4 == 0) && (out_stride_b % 4 == 0);
+    if (vec) {
+        const int threads = std::min(256, ceil_div(D / 4, 64) * 64);
+        hipLaunchKernelGGL(attn_dvalues_kernel<4>, grid, dim3(threads), 0, s, k);
+    } else {
+        const int threads = std::min(256, ceil_div(D, 64) * 64);
+        hipLaunchKernelGGL(attn_dvalues_kernel<1>, grid, dim3(threads), 0, s, k);
+    }
+    return check_launch("attn_dvalues");
+}
+
+}  // namespace mmqg

@@ -1,0 +1,126 @@
+// extern "C" surface of libmmqg_hip.so: thin, checked forwarding to the launchers.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mmqg_common.h"
+#include "mmqg_kernels.h"
+
+namespace mmqg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s);
+int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s);
+int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s);
+int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, hipStream_t s);
+
+}  // namespace mmqg
+
+using namespace mmqg;
+static inline hipStream_t S(mmqg_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+int mmqg_abi_version(void) { return MMQG_ABI_VERSION; }
+const char* mmqg_last_error(void) { return get_error(); }
+
+int mmqg_gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                  const float* A2, int lda2, const float* B2, int ldb2, int K2, const float* bias, const float* bias2,
+                  int beta, float* C, int ldc, int split_k, mmqg_stream stream) {
+    return gemm_f32(a_layout, b_layout, M, N, K, A, lda, B, ldb, A2, lda2, B2, ldb2, K2, bias, bias2, beta, C, ldc,
+                    split_k, S(stream));
+}
+
+int mmqg_embedding_fwd(const float* table, const int64_t* ids, float* out, int n, int V, int E, int ld_out,
+                       mmqg_stream stream) {
+    return embedding_fwd(table, ids, out, n, V, E, ld_out, S(stream));
+}
+int mmqg_embedding_bwd(const float* dout, int ld_dout, const int64_t* ids, float* dtable, int n, int V, int E,
+                       mmqg_stream stream) {
+    return embedding_bwd(dout, ld_dout, ids, dtable, n, V, E, S(stream));
+}
+
+int mmqg_attn_softmax_context_fwd(const mmqg_attn_values* v, const float* scores, int ld_s, float* attn, int ld_a,
+                                  float* ctx, int ld_c, mmqg_stream stream) {
+    MMQG_REQUIRE(v, "mmqg_attn_softmax_context_fwd: null descriptor");
+    return attn_softmax_context_fwd(*v, scores, ld_s, attn, ld_a, ctx, ld_c, S(stream));
+}
+int mmqg_attn_context_bwd(const mmqg_attn_values* v, const float* attn, int ld_a, const float* dctx, int ld_c,
+                          const float* dattn, int ld_da, float* dscores, int ld_ds, mmqg_stream stream) {
+    MMQG_REQUIRE(v, "mmqg_attn_context_bwd: null descriptor");
+    return attn_context_bwd(*v, attn, ld_a, dctx, ld_c, dattn, ld_da, dscores, ld_ds, S(stream));
+}
+int mmqg_attn_dvalues(int T, int B, int n_rows, int D, const float* attn, int64_t attn_stride_t, int ld_a, int seg_off,
+                      const float* dctx, int64_t dctx_stride_t, int ld_c, int ctx_off, float* out,
+                      int64_t out_stride_row, int64_t out_stride_b, int accumulate, mmqg_stream stream) {
+    return attn_dvalues(T, B, n_rows, D, attn, attn_stride_t, ld_a, seg_off, dctx, dctx_stride_t, ld_c, ctx_off, out,
+                        out_stride_row, out_stride_b, accumulate, S(stream));
+}
+
+int mmqg_lstm_cell_fwd(int B, int H, float* gates, int ld_g, const float* h_prev, const float* c_prev, float* h_out,
+                       float* c_out, float* h_drop, float* y_out, int64_t y_stride_b, const int32_t* lens, int t,
+                       float dropout_p, uint64_t seed, uint64_t stream_id, mmqg_stream stream) {
+    CellFwd c{};
+    c.B = B; c.H = H; c.gates = gates; c.ld_g = ld_g; c.h_prev = h_prev; c.c_prev = c_prev;
+    c.h_out = h_out; c.c_out = c_out; c.h_drop = h_drop; c.y_out = y_out; c.y_stride_b = y_stride_b;
+    c.lens = lens; c.t = t; c.p = dropout_p; c.seed = seed; c.stream_id = stream_id;
+    return lstm_cell_fwd(c, S(stream));
+}
+int mmqg_lstm_cell_bwd(int B, int H, const float* gates_act, const float* c_prev, const float* c_new, float* dh_rec,
+                       const float* dh_above, int64_t above_stride_b, float dropout_p, uint64_t seed,
+                       uint64_t stream_id, const float* dh_extra, int64_t extra_stride_b, float* dc, float* dgates,
+                       int ld_dg, const int32_t* lens, int t, mmqg_stream stream) {
+    CellBwd c{};
+    c.B = B; c.H = H; c.gates_act = gates_act; c.c_prev = c_prev; c.c_new = c_new; c.dh_rec = dh_rec;
+    c.dh_above = dh_above; c.above_stride_b = above_stride_b; c.p = dropout_p; c.seed = seed; c.stream_id = stream_id;
+    c.dh_extra = dh_extra; c.extra_stride_b = extra_stride_b; c.dc = dc; c.dgates = dgates; c.ld_dg = ld_dg;
+    c.lens = lens; c.t = t;
+    return lstm_cell_bwd(c, S(stream));
+}
+int mmqg_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id, const int32_t* seed_offset,
+                      mmqg_stream stream) {
+    return dropout_mask(out, n, p, seed, stream_id, seed_offset, S(stream));
+}
+
+int mmqg_ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* row_weight, int rows, int V,
+                    float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, mmqg_stream stream) {
+    return ce_fwd_bwd(logits, ld, target, row_weight, rows, V, loss_rows, argmax, dlogits, ld_d, S(stream));
+}
+int mmqg_colsum_add(const float* X, int ld, int M, int N, float* out, mmqg_stream stream) {
+    return colsum_add(X, ld, M, N, out, S(stream));
+}
+int mmqg_reduce_sum(const float* x, int n, float* out, mmqg_stream stream) { return reduce_sum(x, n, out, S(stream)); }
+
+int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                   const int32_t* step, float grad_scale, mmqg_stream stream) {
+    return adam_step(p, g, m, v, n, lr, b1, b2, eps, step, grad_scale, S(stream));
+}
+int mmqg_counter_add(int32_t* counter, int delta, mmqg_stream stream) { return counter_add(counter, delta, S(stream)); }
+
+int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream) {
+    MMQG_REQUIRE(d, "mmqg_lstm_seq_fwd: null descriptor");
+    return lstm_seq_fwd(*d, S(stream));
+}
+int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_stream stream) {
+    MMQG_REQUIRE(d && g, "mmqg_lstm_seq_bwd: null descriptor");
+    return lstm_seq_bwd(*d, *g, S(stream));
+}
+int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream) {
+    MMQG_REQUIRE(d, "mmqg_decoder_seq_fwd: null descriptor");
+    return decoder_seq_fwd(*d, S(stream));
+}
+int mmqg_decoder_seq_bwd(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g, mmqg_stream stream) {
+    MMQG_REQUIRE(d && g, "mmqg_decoder_seq_bwd: null descriptor");
+    return decoder_seq_bwd(*d, *g, S(stream));
+}
+
+}  // extern "C"

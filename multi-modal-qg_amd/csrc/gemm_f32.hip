@@ -1,0 +1,296 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate,
+// bit-for-bit an fmaf chain, so results stay inside the 1e-4 parity budget).
+//
+//   C[M,N] = (beta ? C : 0) + bias[N] + A(M,K) * B(K,N)  [+ A2(M,K2) * B2(K2,N)]
+//
+// Operand layouts (no copies, the caller's leading dimensions are used as they are):
+//   A k-major : element (m,k) at A[m*lda + k]   (activations x[B,in])
+//   A m-major : element (m,k) at A[k*lda + m]   (dgates^T for weight gradients)
+//   B k-major : element (k,n) at B[n*ldb + k]   (torch Linear/LSTM weight [out,in] -> x*W^T)
+//   B n-major : element (k,n) at B[k*ldb + n]   (dgates*W, dgates^T*x)
+// The optional second operand pair shares the layouts and extends the K loop, which is how
+// the LSTM gate pre-activations x*W_ih^T + h*W_hh^T are produced by one launch.
+//
+// Tiling: 256 threads = 4 wavefronts (2x2).  Two shapes:
+//   BIG   128x128x16, each wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs)
+//   SMALL  64x64x32,  each wave 32x32 = 1 MFMA tile; used with split-K (atomic f32 adds)
+//          for the batch-sized (M<=64) products inside the recurrent loops so that more
+//          than a handful of the 256 CUs get work.
+// LDS holds both operands k-major ([k][m] and [k][n], two stages) so an MFMA operand read is
+// one conflict-free ds_read_b32 per lane; global loads are 16 B per lane and are issued for
+// tile t+1 before the MFMAs of tile t, then written to the other LDS stage (one barrier per tile).
+#include "mmqg_common.h"
+#include "mmqg_kernels.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    int M, N, K, K2;
+    const float* A;  int lda;
+    const float* B;  int ldb;
+    const float* A2; int lda2;
+    const float* B2; int ldb2;
+    const float* bias; const float* bias2;
+    float* C; int ldc;
+    int beta;          // 0: overwrite, 1: accumulate
+    int split_k;       // >1: every z-slice adds its partial product with f32 atomics
+    int vec_a, vec_b, vec_a2, vec_b2;   // operand may be read with aligned 16-B loads
+};
+
+// One operand tile of ROWS (m or n) x BK (k), staged through registers.
+template <int ROWS, int BK, bool KMAJOR>
+struct TileLoader {
+    static constexpr int NV = ROWS * BK / 4 / 256;   // float4 per thread
+    static_assert(NV >= 1, "tile too small");
+    // LDS row length ([k][ROWS + pad]).  k-major sources are transposed on the way in with
+    // scalar ds_write_b32; the pad makes those writes hit 32 distinct banks per half-wave.
+    static constexpr int F4_PER_ROW = BK / 4;
+    static constexpr int LD = KMAJOR ? ROWS + (F4_PER_ROW == 8 ? 1 : 2) : ROWS + 4;
+
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
+                                         bool vec) {
+        const int t = threadIdx.x;
+        if constexpr (KMAJOR) {
+            constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+            const int kq = t % F4_PER_ROW, r = t / F4_PER_ROW;
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int row = row0 + p * ROWS_PER_PASS + r;
+                const int k = k0 + 4 * kq;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < nrows) {
+                    const float* src = P + (int64_t)row * ld + k;
+                    if (vec && k + 3 < K) {
+                        x = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (k + 0 < K) x.x = src[0];
+                        if (k + 1 < K) x.y = src[1];
+                        if (k + 2 < K) x.z = src[2];
+                        if (k + 3 < K) x.w = src[3];
+                    }
+                }
+                v[p] = x;
+            }
+        } else {
+            constexpr int F4_PER_K = ROWS / 4;
+            constexpr int K_PER_PASS = 256 / F4_PER_K;
+            const int c4 = t % F4_PER_K, kr = t / F4_PER_K;
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int k = k0 + p * K_PER_PASS + kr;
+                const int row = row0 + 4 * c4;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K) {
+                    const float* src = P + (int64_t)k * ld + row;
+                    if (vec && row + 3 < nrows) {
+                        x = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (row + 0 < nrows) x.x = src[0];
+                        if (row + 1 < nrows) x.y = src[1];
+                        if (row + 2 < nrows) x.z = src[2];
+                        if (row + 3 < nrows) x.w = src[3];
+                    }
+                }
+                v[p] = x;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ S) const {
+        const int t = threadIdx.x;
+        if constexpr (KMAJOR) {
+            constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+            const int kq = t % F4_PER_ROW, r = t / F4_PER_ROW;
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                const int m = p * ROWS_PER_PASS + r;
+                S[(4 * kq + 0) * LD + m] = v[p].x;
+                S[(4 * kq + 1) * LD + m] = v[p].y;
+                S[(4 * kq + 2) * LD + m] = v[p].z;
+                S[(4 * kq + 3) * LD + m] = v[p].w;
+            }
+        } else {
+            constexpr int F4_PER_K = ROWS / 4;
+            constexpr int K_PER_PASS = 256 / F4_PER_K;
+            const int c4 = t % F4_PER_K, kr = t / F4_PER_K;
+#pragma unroll
+            for (int p = 0; p < NV; ++p) {
+                *reinterpret_cast<float4*>(&S[(p * K_PER_PASS + kr) * LD + 4 * c4]) = v[p];
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int BK, bool A_K, bool B_K>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+    using LA = TileLoader<BM, BK, A_K>;
+    using LB = TileLoader<BN, BK, B_K>;
+    constexpr int WTM = BM / 2, WTN = BN / 2;      // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;    // MFMA tiles per wave
+    constexpr int A_ELEMS = BK * LA::LD, B_ELEMS = BK * LB::LD;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    const int nk1 = (p.K + BK - 1) / BK;
+    const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
+    const int nk = nk1 + nk2;
+    int kt_begin = 0, kt_end = nk;
+    if (p.split_k > 1) {
+        const int per = (nk + p.split_k - 1) / p.split_k;
+        kt_begin = blockIdx.z * per;
+        kt_end = min(nk, kt_begin + per);
+        if (kt_begin >= kt_end) return;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    LA la; LB lb;
+    auto fetch = [&](int kt) {
+        if (kt < nk1) {
+            la.load(p.A, p.lda, m0, p.M, kt * BK, p.K, p.vec_a);
+            lb.load(p.B, p.ldb, n0, p.N, kt * BK, p.K, p.vec_b);
+        } else {
+            la.load(p.A2, p.lda2, m0, p.M, (kt - nk1) * BK, p.K2, p.vec_a2);
+            lb.load(p.B2, p.ldb2, n0, p.N, (kt - nk1) * BK, p.K2, p.vec_b2);
+        }
+    };
+
+    fetch(kt_begin);
+    la.store(smem);
+    lb.store(smem + A_ELEMS);
+    __syncthreads();
+
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const float* As = smem + cur * (A_ELEMS + B_ELEMS);
+        const float* Bs = As + A_ELEMS;
+        const bool more = kt + 1 < kt_end;
+        if (more) fetch(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(kk + half) * LA::LD + wr * WTM + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + half) * LB::LD + wc * WTN + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            float* nxt = smem + (cur ^ 1) * (A_ELEMS + B_ELEMS);
+            la.store(nxt);
+            lb.store(nxt + A_ELEMS);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool lead = (p.split_k <= 1) || (blockIdx.z == 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wc * WTN + j * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = lead ? ((p.bias ? p.bias[col] : 0.f) + (p.bias2 ? p.bias2[col] : 0.f)) : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= p.M) continue;
+                float* dst = p.C + (int64_t)row * p.ldc + col;
+                const float val = acc[i][j][r] + bv;
+                if (p.split_k > 1) {
+                    atomicAdd(dst, val);
+                } else {
+                    *dst = p.beta ? (*dst + val) : val;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK>
+int launch(const GemmArgs& a, int a_layout, int b_layout, hipStream_t s) {
+    dim3 grid(mmqg::ceil_div(a.N, BN), mmqg::ceil_div(a.M, BM), a.split_k > 1 ? a.split_k : 1);
+    dim3 block(256);
+    if (a_layout == MMQG_K_MAJOR && b_layout == MMQG_K_MAJOR)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true, true>), grid, block, 0, s, a);
+    else if (a_layout == MMQG_K_MAJOR && b_layout == MMQG_MN_MAJOR)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true, false>), grid, block, 0, s, a);
+    else if (a_layout == MMQG_MN_MAJOR && b_layout == MMQG_MN_MAJOR)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, false, false>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, false, true>), grid, block, 0, s, a);
+    return mmqg::check_launch("gemm_f32");
+}
+
+inline bool can_vec(const float* p, int ld) { return p && mmqg::aligned16(p) && (ld % 4 == 0); }
+
+}  // namespace
+
+namespace mmqg {
+
+int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+             const float* A2, int lda2, const float* B2, int ldb2, int K2, const float* bias, const float* bias2,
+             int beta, float* C, int ldc, int split_k, hipStream_t s) {
+    MMQG_REQUIRE(M >= 0 && N >= 0 && K >= 1, "gemm_f32: bad dimension (need M,N >= 0 and K >= 1)");
+    if (M == 0 || N == 0) return 0;
+    MMQG_REQUIRE(A && B && C, "gemm_f32: null operand");
+    MMQG_REQUIRE((A2 == nullptr) == (B2 == nullptr), "gemm_f32: second operand pair must be both set or both null");
+    MMQG_REQUIRE(a_layout == MMQG_K_MAJOR || a_layout == MMQG_MN_MAJOR, "gemm_f32: bad a_layout");
+    MMQG_REQUIRE(b_layout == MMQG_K_MAJOR || b_layout == MMQG_MN_MAJOR, "gemm_f32: bad b_layout");
+    MMQG_REQUIRE(lda >= (a_layout == MMQG_K_MAJOR ? K : M), "gemm_f32: lda too small");
+    MMQG_REQUIRE(ldb >= (b_layout == MMQG_K_MAJOR ? K : N), "gemm_f32: ldb too small");
+    MMQG_REQUIRE(ldc >= N, "gemm_f32: ldc too small");
+    GemmArgs a;
+    a.M = M; a.N = N; a.K = K; a.K2 = A2 ? K2 : 0;
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
+    a.A2 = A2; a.lda2 = lda2; a.B2 = B2; a.ldb2 = ldb2;
+    a.bias = bias; a.bias2 = bias2; a.C = C; a.ldc = ldc; a.beta = beta ? 1 : 0;
+    a.vec_a = can_vec(A, lda); a.vec_b = can_vec(B, ldb);
+    a.vec_a2 = can_vec(A2, lda2); a.vec_b2 = can_vec(B2, ldb2);
+
+    const bool small = (M <= 64) || (N <= 64) || ((int64_t)ceil_div(M, 128) * ceil_div(N, 128) < 96);
+    const int bk = small ? 32 : 16;
+    const int nk = ceil_div(K, bk) + (A2 ? ceil_div(K2, bk) : 0);
+    if (split_k < 0) {   // automatic: aim for ~512 workgroups, at least 4 k-tiles per slice
+        split_k = 1;
+        if (small) {
+            const int64_t tiles = (int64_t)ceil_div(M, 64) * ceil_div(N, 64);
+            while (tiles * split_k < 384 && nk / (split_k * 2) >= 4 && split_k < 16) split_k *= 2;
+        }
+    }
+    if (split_k > nk) split_k = nk > 0 ? nk : 1;
+    a.split_k = split_k;
+    if (split_k > 1 && !beta) {
+        // partial products are added atomically, so the destination must start from zero
+        if (ldc == N) {
+            hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s);
+            MMQG_REQUIRE(e == hipSuccess, "gemm_f32: memset failed: %s", hipGetErrorString(e));
+        } else {
+            hipError_t e = hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N, M, s);
+            MMQG_REQUIRE(e == hipSuccess, "gemm_f32: memset2d failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (small) return launch<64, 64, 32>(a, a_layout, b_layout, s);
+    return launch<128, 128, 16>(a, a_layout, b_layout, s);
+}
+
+}  // namespace mmqg

@@ -1,0 +1,156 @@
+// Cross entropy over the vocabulary logits with argmax (train.py:174,264; the greedy pick of
+// train.py:107-108) plus the small reductions the gradient path needs (bias gradients =
+// column sums, the scalar loss).  One workgroup per logits row: three sweeps over the row
+// (max+argmax, sum of exp, gradient write); a row is 40 KB at V=10k so sweeps two and three
+// are L2 hits.
+#include <algorithm>
+
+#include "mmqg_common.h"
+#include "mmqg_kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, int ld,
+                                                         const int64_t* __restrict__ target,
+                                                         const float* __restrict__ row_weight, int V,
+                                                         float* __restrict__ loss_rows, int64_t* __restrict__ argmax,
+                                                         float* dlogits, int ld_d) {
+    __shared__ float shv[4];
+    __shared__ int shi[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = logits + (int64_t)r * ld;
+    // sweep 1: max and the FIRST index that attains it (torch.argmax tie rule)
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+        const float x = row[c];
+        if (x > best || (x == best && c < bi)) { best = x; bi = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { shv[wave] = best; shi[wave] = bi; }
+    __syncthreads();
+    best = shv[0]; bi = shi[0];
+    for (int w = 1; w < 4; ++w)
+        if (shv[w] > best || (shv[w] == best && shi[w] < bi)) { best = shv[w]; bi = shi[w]; }
+    __syncthreads();
+    // sweep 2: sum exp
+    float part = 0.f;
+    for (int c = tid; c < V; c += 256) part += expf(row[c] - best);
+    part = wave_sum(part);
+    if (lane == 0) shv[wave] = part;
+    __syncthreads();
+    const float sum = shv[0] + shv[1] + shv[2] + shv[3];
+    const float lse = best + logf(sum);
+    const float wgt = row_weight ? row_weight[r] : 1.f;
+    int64_t tg = target ? target[r] : -1;
+    const bool tg_ok = tg >= 0 && tg < V;
+    if (tid == 0) {
+        if (argmax) argmax[r] = bi;
+        if (loss_rows) loss_rows[r] = (tg_ok && wgt != 0.f) ? wgt * (lse - row[tg]) : 0.f;
+    }
+    // sweep 3: gradient (may overwrite the logits row in place: every thread has finished
+    // reading other columns only after this barrier)
+    if (dlogits) {
+        __syncthreads();
+        float* drow = dlogits + (int64_t)r * ld_d;
+        const float inv = 1.0f / sum;
+        for (int c = tid; c < V; c += 256) {
+            float g = 0.f;
+            if (tg_ok && wgt != 0.f) g = wgt * (expf(row[c] - best) * inv - (c == tg ? 1.f : 0.f));
+            drow[c] = g;
+        }
+    }
+}
+
+// out[n] += sum_m X[m][n]; rows split over blockIdx.y, finished with f32 atomics
+__global__ __launch_bounds__(256) void colsum_add_kernel(const float* __restrict__ X, int ld, int M, int N,
+                                                         float* __restrict__ out, int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float acc = 0.f;
+    for (int m = m0; m < m1; ++m) acc += X[(int64_t)m * ld + n];
+    atomicAdd(out + n, acc);
+}
+
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float part = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) part += x[i];
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha,
+                                                   int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] += alpha * x[i];
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, int64_t dst_stride,
+                                                       const float* __restrict__ src, int64_t src_stride, int rows,
+                                                       int cols) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[r * dst_stride + c] += src[r * src_stride + c];
+}
+
+}  // namespace
+
+namespace mmqg {
+
+int ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* row_weight, int rows, int V,
+               float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, hipStream_t s) {
+    MMQG_REQUIRE(rows >= 0 && V > 0 && ld >= V, "ce_fwd_bwd: bad shape");
+    if (rows == 0) return 0;
+    MMQG_REQUIRE(logits, "ce_fwd_bwd: null logits");
+    MMQG_REQUIRE(!dlogits || ld_d >= V, "ce_fwd_bwd: ld_d < V");
+    MMQG_REQUIRE(target || (!loss_rows && !dlogits), "ce_fwd_bwd: loss/gradient requested without targets");
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, s, logits, ld, target, row_weight, V, loss_rows,
+                       argmax, dlogits, ld_d);
+    return check_launch("ce_fwd_bwd");
+}
+
+int colsum_add(const float* X, int ld, int M, int N, float* out, hipStream_t s) {
+    MMQG_REQUIRE(M >= 0 && N >= 0 && ld >= N, "colsum_add: bad shape");
+    if (M == 0 || N == 0) return 0;
+    MMQG_REQUIRE(X && out, "colsum_add: null pointer");
+    int slices = std::min(64, std::max(1, M / 32));
+    const int rows_per_block = ceil_div(M, slices);
+    slices = ceil_div(M, rows_per_block);
+    hipLaunchKernelGGL(colsum_add_kernel, dim3(ceil_div(N, 256), slices), dim3(256), 0, s, X, ld, M, N, out,
+                       rows_per_block);
+    return check_launch("colsum_add");
+}
+
+int reduce_sum(const float* x, int n, float* out, hipStream_t s) {
+    MMQG_REQUIRE(n >= 0 && x && out, "reduce_sum: bad arguments");
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, x, n, out);
+    return check_launch("reduce_sum");
+}
+
+int axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s) {
+    MMQG_REQUIRE(n >= 0 && x && y, "axpy: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, y, x, alpha, n);
+    return check_launch("axpy");
+}
+
+int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int rows, int cols,
+                     hipStream_t s) {
+    MMQG_REQUIRE(rows >= 0 && cols >= 0 && dst && src, "add_rows_strided: bad arguments");
+    if (rows == 0 || cols == 0) return 0;
+    const int64_t n = (int64_t)rows * cols;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, dst, dst_stride, src,
+                       src_stride, rows, cols);
+    return check_launch("add_rows_strided");
+}
+
+}  // namespace mmqg

@@ -1,0 +1,78 @@
+// Host-callable launchers of the gfx950 kernels (internal C++ surface; the public boundary is
+// include/mmqg.h).  Every function only enqueues work on the given stream: no allocation, no
+// synchronisation, so a caller may capture any sequence of them into a hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mmqg.h"
+
+namespace mmqg {
+
+// ---- gemm_f32.hip ---------------------------------------------------------------------
+int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+             const float* A2, int lda2, const float* B2, int ldb2, int K2, const float* bias, const float* bias2,
+             int beta, float* C, int ldc, int split_k, hipStream_t s);
+
+// ---- lstm_cell.hip --------------------------------------------------------------------
+struct CellFwd {
+    int B, H;
+    float* gates; int ld_g;                 // [B][4H] in: summed pre-activations (i,f,g,o blocks);
+                                            // out: sigma(i),sigma(f),tanh(g),sigma(o); 0 for finished rows
+    const float* h_prev; const float* c_prev;   // [B][H]
+    float* h_out; float* c_out;             // [B][H]
+    float* h_drop;                          // nullable [B][H]: h_out * dropout scale (input of the next layer)
+    float* y_out; int64_t y_stride_b;       // nullable: y[b*stride + j] = row active ? h_out : 0
+    const int32_t* lens; int t;             // nullable: row b is active while t < lens[b]
+    float p; uint64_t seed; uint64_t stream_id;
+    const int32_t* seed_off;                // nullable device word mixed into the seed at run time
+};
+int lstm_cell_fwd(const CellFwd& a, hipStream_t s);
+
+struct CellBwd {
+    int B, H;
+    const float* gates_act;                 // [B][4H]
+    const float* c_prev; const float* c_new;    // [B][H]
+    float* dh_rec;                          // in: dL/dh from step t+1; out: pass-through part for step t-1
+    const float* dh_above; int64_t above_stride_b;   // nullable: gradient of this layer's (dropped) output
+    float p; uint64_t seed; uint64_t stream_id;       // dropout that was applied to that output
+    const int32_t* seed_off;
+    const float* dh_extra; int64_t extra_stride_b;   // nullable: further gradient of h (only for active rows)
+    float* dc;                              // in/out [B][H]
+    float* dgates; int ld_dg;               // out [B][4H]
+    const int32_t* lens; int t;
+};
+int lstm_cell_bwd(const CellBwd& a, hipStream_t s);
+
+int dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id, const int32_t* seed_off,
+                 hipStream_t s);
+
+// ---- attention.hip --------------------------------------------------------------------
+int attn_softmax_context_fwd(const mmqg_attn_values& v, const float* scores, int ld_s, float* attn, int ld_a,
+                             float* ctx, int ld_c, hipStream_t s);
+int attn_context_bwd(const mmqg_attn_values& v, const float* attn, int ld_a, const float* dctx, int ld_c,
+                     const float* dattn, int ld_da, float* dscores, int ld_ds, hipStream_t s);
+// dV[rows < n_rows] = sum_t attn[t][b][seg+row] * dctx[t][b][off..off+D)
+int attn_dvalues(int T, int B, int n_rows, int D, const float* attn, int64_t attn_stride_t, int ld_a, int seg_off,
+                 const float* dctx, int64_t dctx_stride_t, int ld_c, int ctx_off, float* out, int64_t out_stride_row,
+                 int64_t out_stride_b, int accumulate, hipStream_t s);
+
+// ---- embedding.hip --------------------------------------------------------------------
+int embedding_fwd(const float* table, const int64_t* ids, float* out, int n, int V, int E, int ld_out, hipStream_t s);
+int embedding_bwd(const float* dout, int ld, const int64_t* ids, float* dtable, int n, int V, int E, hipStream_t s);
+
+// ---- loss.hip -------------------------------------------------------------------------
+int ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* row_weight, int rows, int V,
+               float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, hipStream_t s);
+int colsum_add(const float* X, int ld, int M, int N, float* out, hipStream_t s);
+int reduce_sum(const float* x, int n, float* out, hipStream_t s);
+int axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s);
+int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int rows, int cols,
+                     hipStream_t s);
+
+// ---- adam.hip -------------------------------------------------------------------------
+int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+              const int32_t* step, float grad_scale, hipStream_t s);
+int counter_add(int32_t* ctr, int delta, hipStream_t s);
+
+}  // namespace mmqg

@@ -1,0 +1,310 @@
+// Whole-sequence executors: enqueue every kernel of a time loop from C++ so the host pays one
+// FFI call (or one hipGraph replay) per sequence instead of one Python round trip per token,
+// which is how the reference drives its modules (train.py:164-175).
+//
+// Scheduling idea (both executors): anything that does not depend on the recurrence is
+// hoisted out of the time loop into one large GEMM over all T*B rows — the input products
+// X*W_ih^T of a layer, the embedded-word part of the attention scores and of the decoder's
+// layer-0 gates, every weight gradient (dW = dGates^T * X over all steps at once) and the
+// gradient of the value tensors.  The loop itself keeps only h*W_hh^T (+ the attention
+// context product in the decoder), the cell update and the attention kernels.
+#include <algorithm>
+
+#include "mmqg_common.h"
+#include "mmqg_kernels.h"
+
+namespace {
+
+using namespace mmqg;
+
+int copy_or_zero(float* dst, const float* src, size_t n, hipStream_t s) {
+    hipError_t e = src ? hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s)
+                       : hipMemsetAsync(dst, 0, n * sizeof(float), s);
+    MMQG_REQUIRE(e == hipSuccess, "sequence: state init failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int check_lstm(const mmqg_lstm_seq& d, const char* who) {
+    MMQG_REQUIRE(d.T >= 0 && d.B >= 0 && d.H > 0 && d.In > 0, "%s: bad shape", who);
+    MMQG_REQUIRE(d.L >= 1 && d.L <= MMQG_MAX_LAYERS, "%s: L must be in [1,%d]", who, MMQG_MAX_LAYERS);
+    MMQG_REQUIRE(d.x && d.ldx >= d.In, "%s: bad input", who);
+    MMQG_REQUIRE(d.gates && d.hs && d.cs, "%s: null state buffer", who);
+    for (int l = 0; l < d.L; ++l)
+        MMQG_REQUIRE(d.w_ih[l] && d.w_hh[l] && d.b_ih[l] && d.b_hh[l], "%s: null weight (layer %d)", who, l);
+    MMQG_REQUIRE(d.dropout_p >= 0.f && d.dropout_p < 1.f, "%s: dropout_p must be in [0,1)", who);
+    const bool drop = d.training && d.dropout_p > 0.f && d.L > 1;
+    MMQG_REQUIRE(!drop || d.hdrop, "%s: training with dropout needs the hdrop buffer", who);
+    return 0;
+}
+
+inline bool lstm_drop(const mmqg_lstm_seq& d) { return d.training && d.dropout_p > 0.f && d.L > 1; }
+
+}  // namespace
+
+namespace mmqg {
+
+int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s) {
+    MMQG_TRY(check_lstm(d, "lstm_seq_fwd"));
+    if (d.B == 0) return 0;
+    const int T = d.T, B = d.B, H = d.H, L = d.L;
+    const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
+    const bool drop = lstm_drop(d);
+    for (int l = 0; l < L; ++l) {
+        float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
+        float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
+        MMQG_TRY(copy_or_zero(hs_l, d.h0 ? d.h0 + l * BH : nullptr, (size_t)BH, s));
+        MMQG_TRY(copy_or_zero(cs_l, d.c0 ? d.c0 + l * BH : nullptr, (size_t)BH, s));
+        if (T == 0) continue;
+        const float* X; int ldx, in;
+        if (l == 0) { X = d.x; ldx = d.ldx; in = d.In; }
+        else { X = drop ? d.hdrop + (int64_t)(l - 1) * T * BH : d.hs + (int64_t)(l - 1) * (T + 1) * BH + BH; ldx = H; in = H; }
+        float* gates_l = d.gates + (int64_t)l * T * G;
+        // all input products of the layer at once: gates[t] = X[t]*W_ih^T + b_ih + b_hh
+        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, 4 * H, in, X, ldx, d.w_ih[l], in, nullptr, 0, nullptr, 0, 0,
+                          d.b_ih[l], d.b_hh[l], 0, gates_l, 4 * H, -1, s));
+        for (int t = 0; t < T; ++t) {
+            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, 4 * H, H, hs_l + t * BH, H, d.w_hh[l], H, nullptr, 0,
+                              nullptr, 0, 0, nullptr, nullptr, 1, gates_l + t * G, 4 * H, -1, s));
+            CellFwd c{};
+            c.B = B; c.H = H; c.gates = gates_l + t * G; c.ld_g = 4 * H;
+            c.h_prev = hs_l + t * BH; c.c_prev = cs_l + t * BH;
+            c.h_out = hs_l + (t + 1) * BH; c.c_out = cs_l + (t + 1) * BH;
+            c.h_drop = (drop && l < L - 1) ? d.hdrop + (int64_t)l * T * BH + t * BH : nullptr;
+            c.y_out = (l == L - 1 && d.y) ? d.y + t * d.y_stride_t : nullptr;
+            c.y_stride_b = d.y_stride_b;
+            c.lens = d.lens; c.t = t;
+            c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
+            MMQG_TRY(lstm_cell_fwd(c, s));
+        }
+    }
+    return 0;
+}
+
+int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s) {
+    MMQG_TRY(check_lstm(d, "lstm_seq_bwd"));
+    if (d.B == 0 || d.T == 0) return 0;
+    MMQG_REQUIRE(g.dgates && g.dh && g.dc, "lstm_seq_bwd: null scratch buffer");
+    MMQG_REQUIRE(d.L == 1 || g.dxl, "lstm_seq_bwd: multi-layer backward needs dxl");
+    MMQG_REQUIRE(!g.dx || g.lddx >= d.In, "lstm_seq_bwd: lddx < In");
+    const int T = d.T, B = d.B, H = d.H, L = d.L;
+    const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
+    const bool drop = lstm_drop(d);
+    for (int l = L - 1; l >= 0; --l) {
+        const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
+        const float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
+        const float* gates_l = d.gates + (int64_t)l * T * G;
+        float* dg_l = g.dgates + (int64_t)l * T * G;
+        MMQG_TRY(copy_or_zero(g.dh, g.dhT ? g.dhT + l * BH : nullptr, (size_t)BH, s));
+        MMQG_TRY(copy_or_zero(g.dc, g.dcT ? g.dcT + l * BH : nullptr, (size_t)BH, s));
+        for (int t = T - 1; t >= 0; --t) {
+            CellBwd c{};
+            c.B = B; c.H = H; c.gates_act = gates_l + t * G;
+            c.c_prev = cs_l + t * BH; c.c_new = cs_l + (t + 1) * BH;
+            c.dh_rec = g.dh;
+            if (l < L - 1) {
+                c.dh_above = g.dxl + t * BH; c.above_stride_b = H;
+                c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
+            } else if (g.dy) {
+                c.dh_extra = g.dy + t * g.dy_stride_t; c.extra_stride_b = g.dy_stride_b;
+            }
+            c.dc = g.dc; c.dgates = dg_l + t * G; c.ld_dg = 4 * H;
+            c.lens = d.lens; c.t = t;
+            MMQG_TRY(lstm_cell_bwd(c, s));
+            // dh(t-1) += dgates(t) * W_hh
+            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, 4 * H, dg_l + t * G, 4 * H, d.w_hh[l], H, nullptr, 0,
+                              nullptr, 0, 0, nullptr, nullptr, 1, g.dh, H, -1, s));
+        }
+        if (g.dh0) MMQG_TRY(copy_or_zero(g.dh0 + l * BH, g.dh, (size_t)BH, s));
+        if (g.dc0) MMQG_TRY(copy_or_zero(g.dc0 + l * BH, g.dc, (size_t)BH, s));
+        const float* X; int ldx, in;
+        if (l == 0) { X = d.x; ldx = d.ldx; in = d.In; }
+        else { X = drop ? d.hdrop + (int64_t)(l - 1) * T * BH : d.hs + (int64_t)(l - 1) * (T + 1) * BH + BH; ldx = H; in = H; }
+        // gradient wrt the layer input, all steps at once
+        if (l > 0) {
+            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, T * B, H, 4 * H, dg_l, 4 * H, d.w_ih[l], H, nullptr, 0, nullptr,
+                              0, 0, nullptr, nullptr, 0, g.dxl, H, -1, s));
+        } else if (g.dx) {
+            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, T * B, in, 4 * H, dg_l, 4 * H, d.w_ih[0], in, nullptr, 0,
+                              nullptr, 0, 0, nullptr, nullptr, 0, g.dx, g.lddx, -1, s));
+        }
+        // weight gradients: dW += dGates^T * X over all T*B rows
+        if (g.dw_ih[l])
+            MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, in, T * B, dg_l, 4 * H, X, ldx, nullptr, 0, nullptr, 0,
+                              0, nullptr, nullptr, 1, g.dw_ih[l], in, -1, s));
+        if (g.dw_hh[l])
+            MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, H, T * B, dg_l, 4 * H, hs_l, H, nullptr, 0, nullptr, 0,
+                              0, nullptr, nullptr, 1, g.dw_hh[l], H, -1, s));
+        if (g.db_ih[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_ih[l], s));
+        if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_hh[l], s));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- decoder
+static int check_decoder(const mmqg_decoder_seq& d, const char* who) {
+    MMQG_REQUIRE(d.T >= 0 && d.B >= 0 && d.H > 0 && d.E > 0, "%s: bad shape", who);
+    MMQG_REQUIRE(d.L >= 1 && d.L <= MMQG_MAX_LAYERS, "%s: L must be in [1,%d]", who, MMQG_MAX_LAYERS);
+    MMQG_REQUIRE(d.values.B == d.B && d.values.H > 0, "%s: values.B must equal B", who);
+    MMQG_REQUIRE(d.xemb && d.w_attn && d.b_attn && d.h0 && d.c0, "%s: null input", who);
+    MMQG_REQUIRE(d.scores && d.attn && d.ctx && d.gates && d.hs && d.cs, "%s: null buffer", who);
+    MMQG_REQUIRE(d.ld_attn >= d.values.Lt + 2 * d.values.Lav, "%s: ld_attn too small", who);
+    for (int l = 0; l < d.L; ++l)
+        MMQG_REQUIRE(d.w_ih[l] && d.w_hh[l] && d.b_ih[l] && d.b_hh[l], "%s: null weight (layer %d)", who, l);
+    MMQG_REQUIRE(d.dropout_p >= 0.f && d.dropout_p < 1.f, "%s: dropout_p must be in [0,1)", who);
+    const bool drop = d.training && d.dropout_p > 0.f && d.L > 1;
+    MMQG_REQUIRE(!drop || d.hdrop, "%s: training with dropout needs the hdrop buffer", who);
+    return 0;
+}
+
+int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
+    MMQG_TRY(check_decoder(d, "decoder_seq_fwd"));
+    if (d.B == 0) return 0;
+    const int T = d.T, B = d.B, H = d.H, L = d.L, E = d.E;
+    const mmqg_attn_values& v = d.values;
+    const int S = v.Lt + 2 * v.Lav, C = v.H + v.Da + v.Dv, Q = E + H, In0 = E + C;
+    const int ldS = d.ld_attn;
+    const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
+    const bool drop = d.training && d.dropout_p > 0.f && L > 1;
+    for (int l = 0; l < L; ++l) {
+        MMQG_TRY(copy_or_zero(d.hs + (int64_t)l * (T + 1) * BH, d.h0 + l * BH, (size_t)BH, s));
+        MMQG_TRY(copy_or_zero(d.cs + (int64_t)l * (T + 1) * BH, d.c0 + l * BH, (size_t)BH, s));
+    }
+    if (T == 0) return 0;
+    // hoisted: embedded-word part of the scores (+ bias) and of the layer-0 gates (+ b_ih)
+    MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, S, E, d.xemb, E, d.w_attn, Q, nullptr, 0, nullptr, 0, 0,
+                      d.b_attn, nullptr, 0, d.scores, ldS, -1, s));
+    MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, 4 * H, E, d.xemb, E, d.w_ih[0], In0, nullptr, 0, nullptr, 0, 0,
+                      d.b_ih[0], d.b_hh[0], 0, d.gates, 4 * H, -1, s));
+    const float* htop_base = d.hs + (int64_t)(L - 1) * (T + 1) * BH;
+    for (int t = 0; t < T; ++t) {
+        float* sc = d.scores + (int64_t)t * B * ldS;
+        float* at = d.attn + (int64_t)t * B * ldS;
+        float* cx = d.ctx + (int64_t)t * B * C;
+        // scores += h_top(t-1) * W_attn[:, E:]^T     (decoder.py:78,84,92: query = [emb | h_top])
+        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, S, H, htop_base + t * BH, H, d.w_attn + E, Q, nullptr, 0,
+                          nullptr, 0, 0, nullptr, nullptr, 1, sc, ldS, -1, s));
+        MMQG_TRY(attn_softmax_context_fwd(v, sc, ldS, at, ldS, cx, C, s));
+        for (int l = 0; l < L; ++l) {
+            float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
+            float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
+            float* gates = d.gates + (int64_t)l * T * G + t * G;
+            if (l == 0) {
+                // gates0 += ctx * W_ih0[:, E:]^T + h0 * W_hh0^T
+                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, 4 * H, C, cx, C, d.w_ih[0] + E, In0, hs_l + t * BH, H,
+                                  d.w_hh[0], H, H, nullptr, nullptr, 1, gates, 4 * H, -1, s));
+            } else {
+                const float* xin = drop ? d.hdrop + (int64_t)(l - 1) * T * BH + t * BH
+                                        : d.hs + (int64_t)(l - 1) * (T + 1) * BH + (t + 1) * BH;
+                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, 4 * H, H, xin, H, d.w_ih[l], H, hs_l + t * BH, H,
+                                  d.w_hh[l], H, H, d.b_ih[l], d.b_hh[l], 0, gates, 4 * H, -1, s));
+            }
+            CellFwd c{};
+            c.B = B; c.H = H; c.gates = gates; c.ld_g = 4 * H;
+            c.h_prev = hs_l + t * BH; c.c_prev = cs_l + t * BH;
+            c.h_out = hs_l + (t + 1) * BH; c.c_out = cs_l + (t + 1) * BH;
+            c.h_drop = (drop && l < L - 1) ? d.hdrop + (int64_t)l * T * BH + t * BH : nullptr;
+            c.lens = d.lens; c.t = t;
+            c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
+            MMQG_TRY(lstm_cell_fwd(c, s));
+        }
+    }
+    return 0;
+}
+
+int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, hipStream_t s) {
+    MMQG_TRY(check_decoder(d, "decoder_seq_bwd"));
+    if (d.B == 0 || d.T == 0) return 0;
+    MMQG_REQUIRE(g.dhtop && g.dgates && g.dscores && g.dctx && g.dh && g.dc && g.dxa, "decoder_seq_bwd: null buffer");
+    const int T = d.T, B = d.B, H = d.H, L = d.L, E = d.E;
+    const mmqg_attn_values& v = d.values;
+    const int S = v.Lt + 2 * v.Lav, C = v.H + v.Da + v.Dv, Q = E + H, In0 = E + C;
+    const int ldS = d.ld_attn, ldD = g.ld_ds;
+    MMQG_REQUIRE(ldD >= S, "decoder_seq_bwd: ld_ds too small");
+    const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
+    const bool drop = d.training && d.dropout_p > 0.f && L > 1;
+    MMQG_TRY(copy_or_zero(g.dh, nullptr, (size_t)L * BH, s));
+    MMQG_TRY(copy_or_zero(g.dc, nullptr, (size_t)L * BH, s));
+    for (int t = T - 1; t >= 0; --t) {
+        for (int l = L - 1; l >= 0; --l) {
+            const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
+            const float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
+            float* dg = g.dgates + (int64_t)l * T * G + t * G;
+            CellBwd c{};
+            c.B = B; c.H = H; c.gates_act = d.gates + (int64_t)l * T * G + t * G;
+            c.c_prev = cs_l + t * BH; c.c_new = cs_l + (t + 1) * BH;
+            c.dh_rec = g.dh + l * BH;
+            if (l < L - 1) {
+                c.dh_above = g.dxa + l * BH; c.above_stride_b = H;
+                c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
+            } else {
+                c.dh_extra = g.dhtop + t * BH; c.extra_stride_b = H;
+            }
+            c.dc = g.dc + l * BH; c.dgates = dg; c.ld_dg = 4 * H;
+            c.lens = d.lens; c.t = t;
+            MMQG_TRY(lstm_cell_bwd(c, s));
+            (void)hs_l;
+            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, 4 * H, dg, 4 * H, d.w_hh[l], H, nullptr, 0, nullptr, 0, 0,
+                              nullptr, nullptr, 1, g.dh + l * BH, H, -1, s));
+            if (l > 0) {
+                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, 4 * H, dg, 4 * H, d.w_ih[l], H, nullptr, 0, nullptr,
+                                  0, 0, nullptr, nullptr, 0, g.dxa + (l - 1) * BH, H, -1, s));
+            } else {
+                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, C, 4 * H, dg, 4 * H, d.w_ih[0] + E, In0, nullptr, 0,
+                                  nullptr, 0, 0, nullptr, nullptr, 0, g.dctx + (int64_t)t * B * C, C, -1, s));
+            }
+        }
+        float* ds = g.dscores + (int64_t)t * B * ldD;
+        MMQG_TRY(attn_context_bwd(v, d.attn + (int64_t)t * B * ldS, ldS, g.dctx + (int64_t)t * B * C, C, nullptr, 0, ds, ldD, s));
+        // gradient of the query's h_top(t-1) half: feeds the top layer's recurrent gradient
+        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, S, ds, ldD, d.w_attn + E, Q, nullptr, 0, nullptr, 0, 0,
+                          nullptr, nullptr, 1, g.dh + (int64_t)(L - 1) * BH, H, -1, s));
+    }
+    const int R = T * B;
+    const float* htop_prev = d.hs + (int64_t)(L - 1) * (T + 1) * BH;   // rows t = h_top(t-1)
+    // embedded-word gradient: layer-0 gate path + score path
+    if (g.dxemb) {
+        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, R, E, 4 * H, g.dgates, 4 * H, d.w_ih[0], In0, nullptr, 0, nullptr,
+                          0, 0, nullptr, nullptr, 0, g.dxemb, E, -1, s));
+        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, R, E, S, g.dscores, ldD, d.w_attn, Q, nullptr, 0, nullptr, 0, 0,
+                          nullptr, nullptr, 1, g.dxemb, E, -1, s));
+    }
+    if (g.dw_attn) {
+        MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, S, E, R, g.dscores, ldD, d.xemb, E, nullptr, 0, nullptr, 0, 0,
+                          nullptr, nullptr, 1, g.dw_attn, Q, -1, s));
+        MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, S, H, R, g.dscores, ldD, htop_prev, H, nullptr, 0, nullptr, 0, 0,
+                          nullptr, nullptr, 1, g.dw_attn + E, Q, -1, s));
+    }
+    if (g.db_attn) MMQG_TRY(colsum_add(g.dscores, ldD, R, S, g.db_attn, s));
+    for (int l = 0; l < L; ++l) {
+        const float* dg_l = g.dgates + (int64_t)l * T * G;
+        const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
+        if (g.dw_ih[l]) {
+            if (l == 0) {
+                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, E, R, dg_l, 4 * H, d.xemb, E, nullptr, 0, nullptr, 0,
+                                  0, nullptr, nullptr, 1, g.dw_ih[0], In0, -1, s));
+                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, C, R, dg_l, 4 * H, d.ctx, C, nullptr, 0, nullptr, 0,
+                                  0, nullptr, nullptr, 1, g.dw_ih[0] + E, In0, -1, s));
+            } else {
+                const float* X = drop ? d.hdrop + (int64_t)(l - 1) * T * BH : d.hs + (int64_t)(l - 1) * (T + 1) * BH + BH;
+                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, H, R, dg_l, 4 * H, X, H, nullptr, 0, nullptr, 0, 0,
+                                  nullptr, nullptr, 1, g.dw_ih[l], H, -1, s));
+            }
+        }
+        if (g.dw_hh[l])
+            MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, H, R, dg_l, 4 * H, hs_l, H, nullptr, 0, nullptr, 0, 0,
+                              nullptr, nullptr, 1, g.dw_hh[l], H, -1, s));
+        if (g.db_ih[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, R, 4 * H, g.db_ih[l], s));
+        if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, R, 4 * H, g.db_hh[l], s));
+    }
+    // gradient of the value rows an encoder produced (text rows feed the text encoder's
+    // backward, video rows the frame encoder's); audio features are inputs and get none
+    if (g.dtext && g.n_text_rows > 0)
+        MMQG_TRY(attn_dvalues(T, B, std::min(g.n_text_rows, v.Lt), v.H, d.attn, (int64_t)B * ldS, ldS, 0, g.dctx,
+                              (int64_t)B * C, C, 0, g.dtext, g.dtext_stride_row, g.dtext_stride_b, 0, s));
+    if (g.dvideo && g.n_video_rows > 0)
+        MMQG_TRY(attn_dvalues(T, B, std::min(g.n_video_rows, v.Lav), v.Dv, d.attn, (int64_t)B * ldS, ldS, v.Lt + v.Lav,
+                              g.dctx, (int64_t)B * C, C, v.H + v.Da, g.dvideo, g.dvideo_stride_row, g.dvideo_stride_b, 0, s));
+    return 0;
+}
+
+}  // namespace mmqg

@@ -1,0 +1,424 @@
+"""Batched training step for the drop-in modules: the MI355X counterpart of the reference's
+per-question loop ``train.py:149-181`` (zero_grad -> encoders -> token loops -> summed cross
+entropy -> backward -> three Adam steps), for B questions at once.
+
+The three modules keep their reference classes / state-dict keys; this driver
+
+* re-homes all their parameters into ONE flat fp32 buffer (``flat_p``; gradients ``flat_g``,
+  Adam moments likewise) so zero_grad is one memset, the optimizer is one fused kernel and the
+  data-parallel exchange is a few large RCCL all-reduces instead of one per tensor;
+* lays the three attention score layers out back to back (text | audio | video) so the
+  per-step scores are one GEMM against a stacked [Lt+2Lav, E+H] matrix;
+* keeps the encoder outputs of a batch in one fused value tensor per question
+  (text rows | audio rows | video rows) that the attention kernels stream;
+* runs forward and backward through the C++ sequence executors (``mmqg_lstm_seq_*``,
+  ``mmqg_decoder_seq_*``) — no autograd, no per-token Python — and can capture the whole
+  step into a hipGraph.
+
+Loss: ``(1/B) * sum_b sum_{t < tgt_len[b]} CE(logits[b,t], target[b,t])``; for B == 1 this is
+train.py:174's running sum.  The embedding table is shared by the text encoder and the decoder
+and therefore sits in two of the reference's three Adam optimizers (train.py:236,245,255,
+266-267): it is stepped twice per iteration, each time with its own moments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import K_MAJOR, MN_MAJOR, check, ptr
+
+_TEXT_STREAM = 1 << 40
+_DEC_STREAM = 2 << 40
+
+
+def _round4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class BatchedTrainer:
+    def __init__(self, av_enc_model, text_enc_model, dec_model, *, batch_size: int, n_frames: int, ctx_len: int,
+                 tgt_len: int, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, start_id: int = 1,
+                 seed: int = 0, mask_mode: Optional[int] = None, process_group=None, use_graph: bool = False):
+        self.video = getattr(av_enc_model, "video_enc", av_enc_model)
+        self.av_model, self.text, self.dec = av_enc_model, text_enc_model, dec_model
+        dec = dec_model
+        self.dev = dec.out_layer.weight.device
+        if self.dev.type != "cuda":
+            raise _lib.BackendError("mmqg: BatchedTrainer needs the modules on a ROCm device (model.to('cuda'))")
+        _lib.load()
+        self.B, self.Tf, self.Tc, self.Td = batch_size, n_frames, ctx_len, tgt_len
+        self.L, self.H, self.E, self.V = dec.num_layers, dec.hidden_dim, dec.word_emb_dim, dec.n_vocab
+        self.Lt, self.Lav, self.Da, self.Dv = dec.text_max_length, dec.av_max_length, dec.audio_emb_dim, dec.video_emb_dim
+        self.Hv, self.Fin = self.video.hidden_dim, self.video.video_emb_dim
+        if self.text.num_layers != self.L or self.text.hidden_dim != self.H:
+            raise ValueError("text encoder and decoder must share num_layers and hidden_dim (train.py:169 hands the "
+                             "encoder state to the decoder)")
+        if self.Hv != self.Dv:
+            raise ValueError("decoder video_emb_dim must equal the frame encoder's hidden_dim")
+        if self.Tc > self.Lt or self.Tf > self.Lav:
+            raise ValueError("sequence longer than the attention width")
+        if self.text.word_embeddings.weight is not dec.emb_layer.weight:
+            raise ValueError("text encoder and decoder must share one embedding layer (train.py:236)")
+        self.S = self.Lt + 2 * self.Lav
+        self.ldS = _round4(self.S)
+        self.Cw = self.H + self.Da + self.Dv
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.start_id, self.seed = start_id, seed
+        self.mask_mode = dec.mask_mode if mask_mode is None else mask_mode
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.drop_text = float(self.text.dropout_p)
+        self.drop_dec = float(dec.dropout_p)
+        self.training = True
+        self.grad_hook: Optional[Callable[["BatchedTrainer", str], None]] = None
+        self._flatten_parameters()
+        self._allocate()
+        self._describe()
+        self.use_graph = use_graph
+        self._graph = None
+
+    # ------------------------------------------------------------------ parameter layout
+    def _flatten_parameters(self):
+        dec, text, vid = self.dec, self.text, self.video
+        groups: List[Tuple[str, List[torch.nn.Parameter]]] = []
+        groups.append(("dec", [dec.text_attn.weight, dec.audio_attn.weight, dec.vid_attn.weight]))   # stacked W_attn
+        groups.append(("dec", [dec.text_attn.bias, dec.audio_attn.bias, dec.vid_attn.bias]))          # stacked b_attn
+        for p in dec.lstm.flat() + [dec.out_layer.weight, dec.out_layer.bias]:
+            groups.append(("dec", [p]))
+        for p in text.lstm.flat():
+            groups.append(("text", [p]))
+        seen = {id(p) for _, ps in groups for p in ps}
+        emb = dec.emb_layer.weight
+        for p in vid.parameters():
+            if id(p) not in seen:
+                groups.append(("vid", [p]))
+                seen.add(id(p))
+        groups.append(("emb", [emb]))
+        off = 0
+        self.segments: Dict[str, Tuple[int, int]] = {}
+        placed = []
+        for name, ps in groups:
+            off = _round4(off)
+            start = off
+            for p in ps:
+                placed.append((p, off))
+                off += p.numel()
+            lo, hi = self.segments.get(name, (start, start))
+            self.segments[name] = (min(lo, start), off)
+        total = _round4(off)
+        self.flat_p = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(total, device=self.dev, dtype=torch.float32)
+        for p, o in placed:
+            n = p.numel()
+            self.flat_p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[o:o + n].view(p.shape)
+            p.grad = self.flat_g[o:o + n].view(p.shape)
+        e0, e1 = self.segments["emb"]
+        self.emb_m2 = torch.zeros(e1 - e0, device=self.dev, dtype=torch.float32)   # second optimizer's moments
+        self.emb_v2 = torch.zeros(e1 - e0, device=self.dev, dtype=torch.float32)
+        self.step_dev = torch.zeros(1, device=self.dev, dtype=torch.int32)
+        self.n_params = total
+
+    # ------------------------------------------------------------------------ workspaces
+    def _allocate(self):
+        B, Tf, Tc, Td, L, H, E, V = self.B, self.Tf, self.Tc, self.Td, self.L, self.H, self.E, self.V
+        Hv, Fin, Cw, ldS = self.Hv, self.Fin, self.Cw, self.ldS
+        dev = self.dev
+
+        def f(*shape):
+            return torch.zeros(*shape, device=dev, dtype=torch.float32)
+
+        w = self.ws = {}
+        # inputs (static buffers, so a captured graph can be replayed on new data)
+        w["feats"] = f(Tf, B, Fin)
+        w["ids_c"] = torch.zeros(Tc, B, device=dev, dtype=torch.int64)
+        w["ids_d"] = torch.zeros(Td, B, device=dev, dtype=torch.int64)
+        w["target"] = torch.zeros(Td, B, device=dev, dtype=torch.int64)
+        w["ctx_len"] = torch.zeros(B, device=dev, dtype=torch.int32)
+        w["tgt_len"] = torch.zeros(B, device=dev, dtype=torch.int32)
+        w["n_frames"] = torch.zeros(B, device=dev, dtype=torch.int32)
+        w["row_w"] = f(Td, B)
+        # fused value tensor: per question text rows | audio rows | video rows
+        self.val_stride = self.Lt * H + self.Lav * self.Da + self.Lav * self.Dv
+        w["values"] = f(B, self.val_stride)
+        self.off_audio = self.Lt * H
+        self.off_video = self.off_audio + self.Lav * self.Da
+        # frame LSTM
+        w["gates_v"], w["hs_v"], w["cs_v"] = f(1, Tf, B, 4 * Hv), f(1, Tf + 1, B, Hv), f(1, Tf + 1, B, Hv)
+        # text encoder
+        w["xemb_c"] = f(Tc, B, E)
+        w["gates_t"], w["hs_t"], w["cs_t"] = f(L, Tc, B, 4 * H), f(L, Tc + 1, B, H), f(L, Tc + 1, B, H)
+        w["hdrop_t"] = f(max(L - 1, 1), Tc, B, H)
+        # decoder
+        w["xemb_d"] = f(Td, B, E)
+        w["scores"], w["attn"], w["ctx"] = f(Td, B, ldS), f(Td, B, ldS), f(Td, B, Cw)
+        w["gates_d"], w["hs_d"], w["cs_d"] = f(L, Td, B, 4 * H), f(L, Td + 1, B, H), f(L, Td + 1, B, H)
+        w["hdrop_d"] = f(max(L - 1, 1), Td, B, H)
+        w["logits"] = f(Td * B, V)
+        w["loss_rows"] = f(Td * B)
+        w["argmax"] = torch.zeros(Td * B, device=dev, dtype=torch.int64)
+        w["loss"] = f(1)
+        # backward
+        w["dhtop"] = f(Td, B, H)
+        w["dgates_d"], w["dscores"], w["dctx"] = f(L, Td, B, 4 * H), f(Td, B, ldS), f(Td, B, Cw)
+        w["dh_d"], w["dc_d"], w["dxa"] = f(L, B, H), f(L, B, H), f(L, B, H)
+        w["dxemb_d"] = f(Td, B, E)
+        w["dtext"], w["dvideo"] = f(Tc, B, H), f(Tf, B, Hv)
+        w["dgates_t"], w["dxl_t"], w["dh_t"], w["dc_t"] = f(L, Tc, B, 4 * H), f(Tc, B, H), f(B, H), f(B, H)
+        w["dxemb_c"] = f(Tc, B, E)
+        w["dgates_v"], w["dh_v"], w["dc_v"], w["dfeats"] = f(1, Tf, B, 4 * Hv), f(B, Hv), f(B, Hv), f(Tf, B, Fin)
+
+    # ----------------------------------------------------------------------- descriptors
+    def _lstm_ptrs(self, d, params, grads=None):
+        for l in range(len(params) // 4):
+            wi, wh, bi, bh = params[4 * l:4 * l + 4]
+            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = wi.data_ptr(), wh.data_ptr(), bi.data_ptr(), bh.data_ptr()
+            if grads is not None:
+                grads.dw_ih[l], grads.dw_hh[l] = wi.grad.data_ptr(), wh.grad.data_ptr()
+                grads.db_ih[l], grads.db_hh[l] = bi.grad.data_ptr(), bh.grad.data_ptr()
+
+    def _describe(self):
+        w, B, H, L = self.ws, self.B, self.H, self.L
+        vals = w["values"]
+        # frame LSTM -> video rows of the value tensor
+        dv, gv = _lib.LstmSeq(), _lib.LstmSeqGrad()
+        dv.T, dv.B, dv.L, dv.H, dv.In = self.Tf, B, 1, self.Hv, self.Fin
+        dv.x, dv.ldx = w["feats"].data_ptr(), self.Fin
+        self._lstm_ptrs(dv, self.video.lstm.flat(), gv)
+        dv.lens = w["n_frames"].data_ptr()
+        dv.dropout_p, dv.training, dv.seed, dv.stream_base = 0.0, 1, self.seed, 0
+        dv.gates, dv.hs, dv.cs = w["gates_v"].data_ptr(), w["hs_v"].data_ptr(), w["cs_v"].data_ptr()
+        dv.y = vals.data_ptr() + 4 * self.off_video
+        dv.y_stride_t, dv.y_stride_b = self.Dv, self.val_stride
+        gv.dy, gv.dy_stride_t, gv.dy_stride_b = w["dvideo"].data_ptr(), B * self.Hv, self.Hv
+        gv.dgates, gv.dh, gv.dc = w["dgates_v"].data_ptr(), w["dh_v"].data_ptr(), w["dc_v"].data_ptr()
+        gv.dx, gv.lddx = w["dfeats"].data_ptr(), self.Fin
+        self.d_vid, self.g_vid = dv, gv
+        # text encoder -> text rows of the value tensor
+        dt, gt = _lib.LstmSeq(), _lib.LstmSeqGrad()
+        dt.T, dt.B, dt.L, dt.H, dt.In = self.Tc, B, L, H, self.E
+        dt.x, dt.ldx = w["xemb_c"].data_ptr(), self.E
+        self._lstm_ptrs(dt, self.text.lstm.flat(), gt)
+        dt.lens = w["ctx_len"].data_ptr()
+        dt.dropout_p, dt.seed, dt.stream_base = self.drop_text, self.seed, _TEXT_STREAM
+        dt.seed_offset = self.step_dev.data_ptr()
+        dt.gates, dt.hs, dt.cs, dt.hdrop = (w[k].data_ptr() for k in ("gates_t", "hs_t", "cs_t", "hdrop_t"))
+        dt.y, dt.y_stride_t, dt.y_stride_b = vals.data_ptr(), H, self.val_stride
+        gt.dy, gt.dy_stride_t, gt.dy_stride_b = w["dtext"].data_ptr(), B * H, H
+        gt.dhT, gt.dcT = w["dh_d"].data_ptr(), w["dc_d"].data_ptr()      # gradient of the state handed to the decoder
+        gt.dgates, gt.dxl, gt.dh, gt.dc = (w[k].data_ptr() for k in ("dgates_t", "dxl_t", "dh_t", "dc_t"))
+        gt.dx, gt.lddx = w["dxemb_c"].data_ptr(), self.E
+        self.d_text, self.g_text = dt, gt
+        # decoder
+        dd, gd = _lib.DecoderSeq(), _lib.DecoderSeqGrad()
+        dd.T, dd.B, dd.L, dd.H, dd.E = self.Td, B, L, H, self.E
+        v = dd.values
+        v.B, v.Lt, v.Lav, v.H, v.Da, v.Dv = B, self.Lt, self.Lav, H, self.Da, self.Dv
+        v.text, v.audio, v.video = vals.data_ptr(), vals.data_ptr() + 4 * self.off_audio, vals.data_ptr() + 4 * self.off_video
+        v.text_stride_b = v.audio_stride_b = v.video_stride_b = self.val_stride
+        v.text_len, v.av_len, v.mask_mode = w["ctx_len"].data_ptr(), w["n_frames"].data_ptr(), self.mask_mode
+        dd.xemb = w["xemb_d"].data_ptr()
+        dec = self.dec
+        dd.w_attn, dd.b_attn = dec.text_attn.weight.data_ptr(), dec.text_attn.bias.data_ptr()
+        self._lstm_ptrs(dd, dec.lstm.flat(), gd)
+        top = L - 1
+        dd.h0 = w["hs_t"].data_ptr()      # patched per layer below: encoder final states
+        dd.lens = w["tgt_len"].data_ptr()
+        dd.dropout_p, dd.seed, dd.stream_base = self.drop_dec, self.seed, _DEC_STREAM
+        dd.seed_offset = self.step_dev.data_ptr()
+        dd.scores, dd.attn, dd.ld_attn, dd.ctx = w["scores"].data_ptr(), w["attn"].data_ptr(), self.ldS, w["ctx"].data_ptr()
+        dd.gates, dd.hs, dd.cs, dd.hdrop = (w[k].data_ptr() for k in ("gates_d", "hs_d", "cs_d", "hdrop_d"))
+        # the encoder's final (h,c) for every layer, gathered into [L,B,H] (train.py:169)
+        w["h0_d"], w["c0_d"] = torch.zeros(L, B, H, device=self.dev), torch.zeros(L, B, H, device=self.dev)
+        dd.h0, dd.c0 = w["h0_d"].data_ptr(), w["c0_d"].data_ptr()
+        gd.dhtop, gd.dgates = w["dhtop"].data_ptr(), w["dgates_d"].data_ptr()
+        gd.dscores, gd.ld_ds, gd.dctx = w["dscores"].data_ptr(), self.ldS, w["dctx"].data_ptr()
+        gd.dh, gd.dc, gd.dxa, gd.dxemb = (w[k].data_ptr() for k in ("dh_d", "dc_d", "dxa", "dxemb_d"))
+        gd.dw_attn, gd.db_attn = dec.text_attn.weight.grad.data_ptr(), dec.text_attn.bias.grad.data_ptr()
+        gd.n_text_rows, gd.dtext = self.Tc, w["dtext"].data_ptr()
+        gd.dtext_stride_row, gd.dtext_stride_b = B * H, H
+        gd.n_video_rows, gd.dvideo = self.Tf, w["dvideo"].data_ptr()
+        gd.dvideo_stride_row, gd.dvideo_stride_b = B * self.Hv, self.Hv
+        self.d_dec, self.g_dec = dd, gd
+        del top
+
+    # ------------------------------------------------------------------------------ modes
+    def train(self, mode: bool = True):
+        self.training = mode
+        for m in (self.av_model, self.text, self.dec):
+            m.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # --------------------------------------------------------------------------- batches
+    def load_batch(self, batch: dict) -> Optional[torch.Tensor]:
+        """Copy one batch into the static input buffers.  ``frames``: (B,Tf,Fin) features or
+        (B,Tf,C,H,W) raw frames (already in the reference's viewed layout); ``audio`` (B,Tf,Da);
+        ``context`` (B,Tc) ids; ``target`` (B,Td) ids; ``ctx_len``/``tgt_len``/``n_frames`` (B,).
+        Returns the raw-frame tensor when the CNN stage must run (else None)."""
+        w, B = self.ws, self.B
+        frames = batch["frames"]
+        raw = None
+        if frames.dim() == 5:
+            raw = frames.to(self.dev)
+        else:
+            w["feats"].copy_(frames.to(self.dev).transpose(0, 1))
+        nf = batch["n_frames"].to(self.dev)
+        w["n_frames"].copy_(nf)
+        w["ctx_len"].copy_(batch["ctx_len"].to(self.dev))
+        w["tgt_len"].copy_(batch["tgt_len"].to(self.dev))
+        ctx = batch["context"].to(self.dev)
+        tgt = batch["target"].to(self.dev)
+        w["ids_c"].copy_(ctx.t())
+        w["target"].copy_(tgt.t())
+        w["ids_d"][0].fill_(self.start_id)                       # train.py:168
+        w["ids_d"][1:].copy_(tgt.t()[:-1])                       # teacher forcing, train.py:175
+        steps = torch.arange(self.Td, device=self.dev).view(-1, 1)
+        w["row_w"].copy_((steps < w["tgt_len"].view(1, -1)).to(torch.float32) / B)
+        # audio features: rows past n_frames must be zero (train.py:156 pads with zeros)
+        audio = batch["audio"].to(self.dev)
+        va = w["values"][:, self.off_audio:self.off_video].view(B, self.Lav, self.Da)
+        keep = (torch.arange(audio.shape[1], device=self.dev).view(1, -1) < nf.view(-1, 1)).unsqueeze(-1)
+        va[:, :audio.shape[1]].copy_(audio * keep)
+        return raw
+
+    # ------------------------------------------------------------------------ one step
+    def _forward(self, training: bool):
+        lib, s, w = _lib.load(), ops._stream(), self.ws
+        L, B, H, V = self.L, self.B, self.H, self.V
+        for d in (self.d_vid, self.d_text, self.d_dec):
+            d.training = int(training)
+        self.d_text.dropout_p = self.drop_text if training else 0.0
+        self.d_dec.dropout_p = self.drop_dec if training else 0.0
+        check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_vid), s), "lstm_seq_fwd(frames)")
+        emb = self.dec.emb_layer.weight
+        ops.embedding_fwd(emb, w["ids_c"], w["xemb_c"].view(-1, self.E))
+        check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_text), s), "lstm_seq_fwd(text)")
+        w["h0_d"].copy_(w["hs_t"][:, self.Tc])
+        w["c0_d"].copy_(w["cs_t"][:, self.Tc])
+        ops.embedding_fwd(emb, w["ids_d"], w["xemb_d"].view(-1, self.E))
+        check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd")
+        htop = w["hs_d"][L - 1, 1:].reshape(self.Td * B, H)
+        out = self.dec.out_layer
+        ops.gemm(K_MAJOR, K_MAJOR, self.Td * B, V, H, htop, H, out.weight, H, w["logits"], V, bias=out.bias)
+
+    def _loss_and_backward(self, feats_grad_sink=None):
+        lib, s, w = _lib.load(), ops._stream(), self.ws
+        L, B, H, V, E = self.L, self.B, self.H, self.V, self.E
+        R = self.Td * B
+        logits = w["logits"]
+        check(lib.mmqg_ce_fwd_bwd(logits.data_ptr(), V, w["target"].data_ptr(), w["row_w"].data_ptr(), R, V,
+                                  w["loss_rows"].data_ptr(), w["argmax"].data_ptr(), logits.data_ptr(), V, s), "ce_fwd_bwd")
+        check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), s), "reduce_sum")
+        out = self.dec.out_layer
+        htop = w["hs_d"][L - 1, 1:].reshape(R, H)
+        # vocabulary projection backward (logits now holds dlogits)
+        ops.gemm(K_MAJOR, MN_MAJOR, R, H, V, logits, V, out.weight, H, w["dhtop"], H)
+        ops.gemm(MN_MAJOR, MN_MAJOR, V, H, R, logits, V, htop, H, out.weight.grad, H, beta=1)
+        ops.colsum_add(logits, out.bias.grad)
+        check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s), "decoder_seq_bwd")
+        demb = self.dec.emb_layer.weight.grad
+        ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
+        if self.grad_hook:
+            self.grad_hook(self, "dec")
+        check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text)")
+        ops.embedding_bwd(w["dxemb_c"].view(-1, E), w["ids_c"], demb)
+        check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s), "lstm_seq_bwd(frames)")
+        if self.grad_hook:
+            self.grad_hook(self, "rest")
+
+    def _adam(self):
+        lib, s = _lib.load(), ops._stream()
+        b1, b2 = self.betas
+        scale = 1.0 / self.world
+        check(lib.mmqg_counter_add(self.step_dev.data_ptr(), 1, s), "counter_add")
+        check(lib.mmqg_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                 self.flat_v.data_ptr(), self.n_params, self.lr, b1, b2, self.eps,
+                                 self.step_dev.data_ptr(), scale, s), "adam_step")
+        e0, e1 = self.segments["emb"]
+        check(lib.mmqg_adam_step(self.flat_p.data_ptr() + 4 * e0, self.flat_g.data_ptr() + 4 * e0,
+                                 self.emb_m2.data_ptr(), self.emb_v2.data_ptr(), e1 - e0, self.lr, b1, b2, self.eps,
+                                 self.step_dev.data_ptr(), scale, s), "adam_step(embedding, 2nd optimizer)")
+
+    def _allreduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_g, group=self.pg)
+
+    def forward_backward(self, batch: Optional[dict] = None):
+        """zero_grad + forward + loss + backward for the batch already loaded (or ``batch``).
+        Gradients are left in ``flat_g`` / every ``param.grad``; returns the loss tensor."""
+        raw = self.load_batch(batch) if batch is not None else None
+        self.flat_g.zero_()
+        feats = None
+        if raw is not None:
+            # CNN stage on PyTorch-ROCm ops with autograd; its output feeds the HIP frame LSTM
+            with torch.enable_grad():
+                feats = self.video.cnn_features(raw, self.ws["n_frames"]).transpose(0, 1).contiguous()
+            self.ws["feats"].copy_(feats.detach())
+        self._forward(self.training)
+        self._loss_and_backward()
+        if feats is not None:
+            feats.backward(self.ws["dfeats"])
+        return self.ws["loss"]
+
+    def step(self, batch: Optional[dict] = None):
+        """One full training iteration (train.py:149-181).  Returns the loss tensor (device)."""
+        if self.use_graph and batch is not None and batch["frames"].dim() != 5:
+            return self._graph_step(batch)
+        loss = self.forward_backward(batch)
+        self._allreduce()
+        self._adam()
+        return loss
+
+    # ------------------------------------------------------------------------ hipGraph
+    def _graph_body(self):
+        self.flat_g.zero_()
+        self._forward(True)
+        self._loss_and_backward()
+
+    def _graph_step(self, batch):
+        self.load_batch(batch)
+        if self._graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):      # warm-up outside capture (lazy module loads, RCCL init)
+                self._graph_body()
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            self._graph_adam = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._graph_body()
+            with torch.cuda.graph(self._graph_adam):
+                self._adam()
+        self._graph.replay()
+        self._allreduce()
+        self._graph_adam.replay()
+        return self.ws["loss"]
+
+    # ------------------------------------------------------------------------- inference
+    @torch.no_grad()
+    def logits(self) -> torch.Tensor:
+        """(B,Td,V) logits of the last forward (before the loss kernel overwrote them with
+        their gradient they are only valid after ``forward_only``)."""
+        return self.ws["logits"].view(self.Td, self.B, self.V).transpose(0, 1)
+
+    @torch.no_grad()
+    def forward_only(self, batch: dict, training: bool = False) -> torch.Tensor:
+        raw = self.load_batch(batch)
+        if raw is not None:
+            was = self.video.training
+            self.video.train(training)
+            feats = self.video.cnn_features(raw, self.ws["n_frames"]).transpose(0, 1)
+            self.video.train(was)
+            self.ws["feats"].copy_(feats)
+        self._forward(training)
+        return self.logits()

@@ -1,0 +1,411 @@
+"""Kernel-level parity: every HIP kernel, called through the C ABI, against the CPU oracle /
+a float64 restatement on the same seeded inputs.  fp32 tolerance 1e-4 (relative to the
+magnitude of the expected tensor), index outputs bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def mm():
+    import mmqg_amd  # noqa: F401
+    from mmqg_amd import _lib, ops
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test on a machine without a ROCm device")
+    _lib.load()
+    return _lib, ops
+
+
+def close(got, want, tol=TOL, what=""):
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(1.0, float(want.abs().max())) if want.numel() else 1.0
+    err = float((got - want).abs().max()) if want.numel() else 0.0
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ------------------------------------------------------------------------------------ GEMM
+GEMM_CASES = [
+    # M, N, K, a_layout, b_layout, lda_pad, ldb_pad, ldc_pad, bias, beta, split, K2
+    (64, 2048, 512, 0, 0, 0, 0, 0, True, 0, 1, 0),
+    (64, 2048, 512, 0, 0, 0, 0, 0, True, 1, -1, 512),      # LSTM gates: dual operand + split-K atomics
+    (64, 485, 512, 0, 0, 0, 300, 3, False, 1, -1, 0),      # attention scores: weight sub-block, ldc 488
+    (1280, 1000, 512, 0, 0, 0, 0, 0, True, 0, 1, 0),       # vocabulary projection shape (V scaled down)
+    (1280, 512, 1000, 0, 1, 0, 0, 0, False, 0, -1, 0),     # dgrad: dlogits * W
+    (1000, 512, 1280, 1, 1, 0, 0, 0, False, 1, -1, 0),     # wgrad: dlogits^T * h
+    (2048, 1452, 640, 1, 1, 0, 0, 0, False, 1, 1, 0),      # LSTM wgrad, big tiles
+    (64, 1152, 2048, 0, 1, 0, 300, 0, False, 0, -1, 0),    # dctx = dgates * W_ih0[:, E:]
+    (485, 300, 640, 1, 1, 3, 0, 512, False, 1, -1, 0),     # dW_attn[:, :E] += dS^T * xemb (lda 488, ldc 812)
+    (3, 7, 5, 0, 0, 0, 0, 0, True, 0, 1, 0),               # tiny, nothing aligned
+    (33, 65, 37, 0, 1, 1, 1, 1, True, 1, 2, 0),            # odd everything, scalar loads
+    (65, 33, 37, 1, 0, 1, 1, 1, False, 0, 1, 19),          # m-major A with k-major B, dual
+    (130, 257, 300, 0, 0, 0, 0, 0, True, 0, 3, 0),
+    (1, 10000, 512, 0, 0, 0, 0, 0, True, 0, -1, 0),        # batch-1 projection (the reference's own shape)
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_against_float64(mm, case):
+    _lib, ops = mm
+    M, N, K, al, bl, pa, pb, pc, use_bias, beta, split, K2 = case
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+
+    def operand(rows, cols, k_major, pad):
+        # k_major: stored [rows][K]; else stored [K][rows]
+        shape = (rows, cols + pad) if k_major else (cols, rows + pad)
+        full = torch.randn(*shape, generator=g)
+        logical = full[:, :cols] if k_major else full[:, :rows].t()
+        return full, logical, shape[1]
+
+    Afull, A, lda = operand(M, K, al == 0, pa)
+    Bfull, Bt, ldb = operand(N, K, bl == 0, pb)          # Bt logical [N,K]
+    want = A.double() @ Bt.double().t()
+    A2d = B2d = None
+    lda2 = ldb2 = 0
+    if K2:
+        A2full, A2, lda2 = operand(M, K2, al == 0, 0)
+        B2full, B2t, ldb2 = operand(N, K2, bl == 0, 0)
+        want = want + A2.double() @ B2t.double().t()
+        A2d, B2d = dev(A2full), dev(B2full)
+    bias = torch.randn(N, generator=g) if use_bias else None
+    bias2 = torch.randn(N, generator=g) if (use_bias and K2) else None
+    ldc = N + pc
+    Cfull = torch.randn(M, ldc, generator=g)
+    if bias is not None:
+        want = want + bias.double()
+    if bias2 is not None:
+        want = want + bias2.double()
+    if beta:
+        want = want + Cfull[:, :N].double()
+    Ad, Bd, Cd = dev(Afull), dev(Bfull), dev(Cfull)
+    ops.gemm(al, bl, M, N, K, Ad, lda, Bd, ldb, Cd, ldc, beta=beta, bias=None if bias is None else dev(bias),
+             bias2=None if bias2 is None else dev(bias2), A2=A2d, lda2=lda2, B2=B2d, ldb2=ldb2, K2=K2, split_k=split)
+    torch.cuda.synchronize()
+    got = Cd.cpu()
+    close(got[:, :N], want.float(), what=f"gemm{case}")
+    if pc:
+        assert torch.equal(got[:, N:], Cfull[:, N:]), "gemm wrote outside its N columns"
+
+
+def test_gemm_rejects_bad_arguments(mm):
+    _lib, ops = mm
+    x = torch.zeros(4, 4, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm(0, 0, 4, 4, 4, x, 2, x, 4, x, 4)            # lda < K
+    with pytest.raises(RuntimeError):
+        ops.gemm(0, 5, 4, 4, 4, x, 4, x, 4, x, 4)            # bad layout
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd(torch.zeros(2, 2), torch.zeros(2, 2), None)   # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------- embedding
+@pytest.mark.parametrize("V,E,n", [(50, 12, 7), (10000, 300, 2048), (97, 301, 33)])
+def test_embedding_gather_and_dense_gradient(mm, V, E, n):
+    _lib, ops = mm
+    g = torch.Generator().manual_seed(V + E)
+    table = torch.randn(V, E, generator=g)
+    ids = torch.randint(0, V, (n,), generator=g)
+    ids[: n // 3] = ids[0]                                    # collisions: the scatter-add must accumulate
+    out = ops.embedding_fwd(dev(table), dev(ids))
+    assert torch.equal(out.cpu(), table[ids])                # a copy: bit-exact
+    dout = torch.randn(n, E, generator=g)
+    dtab = torch.zeros(V, E, device="cuda")
+    ops.embedding_bwd(dev(dout), dev(ids), dtab)
+    want = torch.zeros(V, E, dtype=torch.float64).index_add_(0, ids, dout.double())
+    close(dtab, want.float(), what="embedding_bwd")
+
+
+def test_embedding_out_of_range_ids_give_zero_rows(mm):
+    _lib, ops = mm
+    table = torch.randn(10, 8)
+    ids = torch.tensor([3, -1, 10, 9])
+    out = ops.embedding_fwd(dev(table), dev(ids)).cpu()
+    assert torch.equal(out[0], table[3]) and torch.equal(out[3], table[9])
+    assert out[1].abs().sum() == 0 and out[2].abs().sum() == 0
+
+
+# ------------------------------------------------------------------------------- attention
+def _attn_case(g, B, Lt, Lav, H, Da, Dv):
+    S = Lt + 2 * Lav
+    scores = torch.randn(B, S, generator=g) * 2
+    text = torch.randn(B, Lt, H, generator=g)
+    audio = torch.randn(B, Lav, Da, generator=g)
+    video = torch.randn(B, Lav, Dv, generator=g)
+    text_len = torch.randint(1, Lt + 1, (B,), generator=g).to(torch.int32)
+    av_len = torch.randint(1, Lav + 1, (B,), generator=g).to(torch.int32)
+    return scores, text, audio, video, text_len, av_len
+
+
+def _attn_oracle(scores, text, audio, video, text_len, av_len, mask_mode):
+    from oracle import mmqg_oracle as O
+    Lt, Lav = text.shape[1], audio.shape[1]
+    a_t = O._attn_softmax(scores[:, :Lt], text_len, mask_mode)
+    a_a = O._attn_softmax(scores[:, Lt:Lt + Lav], av_len, mask_mode)
+    a_v = O._attn_softmax(scores[:, Lt + Lav:], av_len, mask_mode)
+    ctx = torch.cat((torch.bmm(a_t.unsqueeze(1), text).squeeze(1), torch.bmm(a_a.unsqueeze(1), audio).squeeze(1),
+                     torch.bmm(a_v.unsqueeze(1), video).squeeze(1)), dim=1)
+    return torch.cat((a_t, a_a, a_v), dim=1), ctx
+
+
+@pytest.mark.parametrize("shape", [(3, 9, 5, 16, 6, 16), (4, 283, 101, 512, 128, 512), (2, 33, 7, 130, 10, 36),
+                                   (64, 32, 8, 512, 128, 512), (1, 283, 101, 512, 128, 512)])
+@pytest.mark.parametrize("mask_mode", [0, 1])
+def test_attention_forward_backward(mm, shape, mask_mode):
+    _lib, ops = mm
+    g = torch.Generator().manual_seed(sum(shape) + mask_mode)
+    scores, text, audio, video, text_len, av_len = _attn_case(g, *shape)
+    leaves = [t.double().requires_grad_(True) for t in (scores, text, audio, video)]
+    attn_w, ctx_w = _attn_oracle(*leaves, text_len, av_len, mask_mode)
+    dctx = torch.randn(ctx_w.shape, generator=g)
+    dattn = torch.randn(attn_w.shape, generator=g) * 0.1
+    (attn_w * dattn.double()).sum().add((ctx_w * dctx.double()).sum()).backward()
+
+    ins = [dev(t).requires_grad_(True) for t in (scores, text, audio, video)]
+    attn, ctx = ops.AttentionFn.apply(ins[0], ins[1], ins[2], ins[3], dev(text_len), dev(av_len), mask_mode)
+    close(attn, attn_w.float(), what="attn weights")
+    close(ctx, ctx_w.float(), what="context")
+    ((attn * dev(dattn)).sum() + (ctx * dev(dctx)).sum()).backward()
+    for name, a, b in zip(("dscores", "dtext", "daudio", "dvideo"), ins, leaves):
+        close(a.grad, b.grad.float(), what=name)
+
+
+def test_attention_accepts_the_fused_value_layout(mm):
+    """One allocation per question holding text | audio | video rows (the layout the batched
+    trainer uses) must give the same result as three separate tensors."""
+    _lib, ops = mm
+    B, Lt, Lav, H, Da, Dv = 5, 33, 9, 64, 16, 64
+    g = torch.Generator().manual_seed(5)
+    scores, text, audio, video, text_len, av_len = _attn_case(g, B, Lt, Lav, H, Da, Dv)
+    fused = torch.cat((text.reshape(B, -1), audio.reshape(B, -1), video.reshape(B, -1)), dim=1).cuda()
+    stride = fused.shape[1]
+    v = _lib.AttnValues()
+    v.B, v.Lt, v.Lav, v.H, v.Da, v.Dv = B, Lt, Lav, H, Da, Dv
+    v.text, v.audio, v.video = fused.data_ptr(), fused.data_ptr() + 4 * Lt * H, fused.data_ptr() + 4 * (Lt * H + Lav * Da)
+    v.text_stride_b = v.audio_stride_b = v.video_stride_b = stride
+    S, Cw = Lt + 2 * Lav, H + Da + Dv
+    sc = scores.cuda()
+    attn = torch.empty_like(sc)
+    ctx = torch.empty(B, Cw, device="cuda")
+    _lib.check(_lib.load().mmqg_attn_softmax_context_fwd(C.byref(v), sc.data_ptr(), S, attn.data_ptr(), S,
+                                                         ctx.data_ptr(), Cw, ops._stream()))
+    attn_w, ctx_w = _attn_oracle(scores, text, audio, video, text_len, av_len, 0)
+    close(attn, attn_w, what="fused attn")
+    close(ctx, ctx_w, what="fused ctx")
+
+
+def test_attention_dvalues_over_steps(mm):
+    _lib, ops = mm
+    T, B, Lt, Lav, H, Da, Dv = 6, 4, 11, 5, 32, 8, 16
+    S, Cw = Lt + 2 * Lav, H + Da + Dv
+    g = torch.Generator().manual_seed(3)
+    attn = torch.rand(T, B, S, generator=g)
+    dctx = torch.randn(T, B, Cw, generator=g)
+    n_rows = 7
+    out = torch.full((n_rows, B, H), 7.0, device="cuda")        # time-major [row][b][H]
+    _lib.check(_lib.load().mmqg_attn_dvalues(T, B, n_rows, H, dev(attn).data_ptr(), B * S, S, 0, dev(dctx).data_ptr(),
+                                             B * Cw, Cw, 0, out.data_ptr(), B * H, H, 0, ops._stream()))
+    want = torch.einsum("tbr,tbh->rbh", attn[:, :, :n_rows].double(), dctx[:, :, :H].double())
+    close(out, want.float(), what="dvalues text")
+    outv = torch.zeros(B, Lav, Dv, device="cuda")
+    a_d, d_d = dev(attn), dev(dctx)
+    _lib.check(_lib.load().mmqg_attn_dvalues(T, B, Lav, Dv, a_d.data_ptr(), B * S, S, Lt + Lav, d_d.data_ptr(), B * Cw, Cw,
+                                             H + Da, outv.data_ptr(), Dv, Lav * Dv, 0, ops._stream()))
+    wantv = torch.einsum("tbr,tbh->brh", attn[:, :, Lt + Lav:].double(), dctx[:, :, H + Da:].double())
+    close(outv, wantv.float(), what="dvalues video")
+
+
+# ------------------------------------------------------------------------------- LSTM cell
+@pytest.mark.parametrize("B,H", [(3, 16), (64, 512), (5, 33)])
+def test_lstm_cell_forward_backward_with_ragged_rows_and_dropout(mm, B, H):
+    _lib, ops = mm
+    from oracle import mmqg_oracle as O
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * H)
+    pre = torch.randn(B, 4 * H, generator=g)
+    h_prev, c_prev = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+    lens = torch.randint(0, 4, (B,), generator=g).to(torch.int32)
+    t, p, seed, stream = 1, 0.25, 1234, 77
+    gates = dev(pre).clone()
+    h_out, c_out, h_drop = (torch.empty(B, H, device="cuda") for _ in range(3))
+    y = torch.full((B, H + 3), -5.0, device="cuda")
+    _lib.check(lib.mmqg_lstm_cell_fwd(B, H, gates.data_ptr(), 4 * H, dev(h_prev).data_ptr(), dev(c_prev).data_ptr(),
+                                      h_out.data_ptr(), c_out.data_ptr(), h_drop.data_ptr(), y.data_ptr(), H + 3,
+                                      dev(lens).data_ptr(), t, p, seed, stream, ops._stream()))
+    mask = ops.dropout_mask(B * H, p, seed, stream, "cuda").view(B, H).cpu()
+    active = (lens > t).view(-1, 1)
+    # oracle: the cell with identity "weights" (pre-activations given directly)
+    hp, cp, pr = (x.double().requires_grad_(True) for x in (h_prev, c_prev, pre))
+    i, f, gg, o = (pr[:, k * H:(k + 1) * H] for k in range(4))
+    c_new = torch.sigmoid(f) * cp + torch.sigmoid(i) * torch.tanh(gg)
+    h_new = torch.sigmoid(o) * torch.tanh(c_new)
+    h_w = torch.where(active, h_new, hp)
+    c_w = torch.where(active, c_new, cp)
+    close(h_out, h_w.float(), what="h")
+    close(c_out, c_w.float(), what="c")
+    close(h_drop, (h_w * mask.double() * active).float(), what="h_drop")
+    close(y[:, :H], (h_w * active).float(), what="y")
+    assert torch.all(y[:, H:] == -5.0)
+    act = torch.cat((torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)), dim=1) * active
+    close(gates, act.float(), what="activated gates")
+    # backward: loss = sum(h_drop*gd) + sum(y*gy) + sum(h*gh) + sum(c*gc)
+    gd, gy, gh, gc = (torch.randn(B, H, generator=g) for _ in range(4))
+    loss = (h_w * mask.double() * active * gd.double()).sum() + (h_w * active * gy.double()).sum() \
+        + (h_w * gh.double()).sum() + (c_w * gc.double()).sum()
+    loss.backward()
+    dh_rec = dev(gh).clone()
+    dc = dev(gc).clone()
+    dgates = torch.empty(B, 4 * H, device="cuda")
+    _lib.check(lib.mmqg_lstm_cell_bwd(B, H, gates.data_ptr(), dev(c_prev).data_ptr(), c_out.data_ptr(), dh_rec.data_ptr(),
+                                      dev(gd).data_ptr(), H, p, seed, stream, dev(gy).data_ptr(), H, dc.data_ptr(),
+                                      dgates.data_ptr(), 4 * H, dev(lens).data_ptr(), t, ops._stream()))
+    close(dgates, pr.grad.float(), what="dgates")
+    close(dc, cp.grad.float(), what="dc_prev")
+    # dh_rec holds only the pass-through part (finished rows); active rows get theirs from dgates*W_hh
+    close(dh_rec, (hp.grad * (~active)).float(), what="dh pass-through")
+
+
+def test_dropout_mask_statistics_and_determinism(mm):
+    _lib, ops = mm
+    n, p = 1 << 20, 0.2
+    a = ops.dropout_mask(n, p, 9, 3, "cuda")
+    b = ops.dropout_mask(n, p, 9, 3, "cuda")
+    c = ops.dropout_mask(n, p, 9, 4, "cuda")
+    off = torch.tensor([5], dtype=torch.int32, device="cuda")
+    d = ops.dropout_mask(n, p, 9, 3, "cuda", seed_offset=off)
+    assert torch.equal(a, b)
+    assert not torch.equal(a, c) and not torch.equal(a, d)
+    vals = sorted(a.unique().cpu().tolist())
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1.25) < 1e-6
+    keep = float((a > 0).float().mean())
+    assert abs(keep - 0.8) < 4 * (0.8 * 0.2 / n) ** 0.5 + 1e-3
+    assert abs(float(a.mean()) - 1.0) < 5e-3
+    assert abs(float(((a > 0) & (c > 0)).float().mean()) - 0.64) < 5e-3      # streams independent
+
+
+# ------------------------------------------------------------------- cross entropy / sums / Adam
+@pytest.mark.parametrize("rows,V", [(7, 50), (1280, 10000), (3, 50001)])
+def test_cross_entropy_argmax_and_gradient(mm, rows, V):
+    _lib, ops = mm
+    g = torch.Generator().manual_seed(rows + V)
+    logits = torch.randn(rows, V, generator=g) * 3
+    target = torch.randint(0, V, (rows,), generator=g)
+    wgt = torch.rand(rows, generator=g)
+    wgt[0] = 0.0
+    logits[1, 5] = logits[1, 9] = logits[1].max() + 1       # tie: first index must win
+    loss_rows, argmax, dlog = ops.ce_fwd_bwd(dev(logits), dev(target), dev(wgt), want_grad=True)
+    ld = logits.double().requires_grad_(True)
+    ce = torch.nn.functional.cross_entropy(ld, target, reduction="none") * wgt.double()
+    ce.sum().backward()
+    close(loss_rows, ce.float(), what="loss rows")
+    close(dlog, ld.grad.float(), what="dlogits")
+    assert torch.equal(argmax.cpu(), torch.argmax(logits, dim=1))
+    assert int(argmax[1]) == 5
+    # in place
+    buf = dev(logits).clone()
+    _, _, d2 = ops.ce_fwd_bwd(buf, dev(target), dev(wgt), want_grad=True, in_place=True)
+    assert d2.data_ptr() == buf.data_ptr()
+    close(buf, ld.grad.float(), what="dlogits in place")
+
+
+def test_colsum_and_reduce_sum(mm):
+    _lib, ops = mm
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(1280, 2048, generator=g)
+    out = torch.ones(2048, device="cuda")
+    ops.colsum_add(dev(X), out)
+    close(out, (X.double().sum(0) + 1).float(), what="colsum")
+    x = torch.randn(1000, generator=g)
+    r = torch.zeros(1, device="cuda")
+    _lib.check(_lib.load().mmqg_reduce_sum(dev(x).data_ptr(), 1000, r.data_ptr(), ops._stream()))
+    close(r, x.double().sum().float().view(1), what="reduce_sum")
+
+
+def test_adam_matches_oracle_over_steps(mm):
+    _lib, ops = mm
+    from oracle import mmqg_oracle as O
+    lib = _lib.load()
+    n = 10007
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(n, generator=g)
+    p_ref, m_ref, v_ref = p0.clone(), torch.zeros(n), torch.zeros(n)
+    pad = (n + 3) // 4 * 4
+    p, m, v = torch.zeros(pad, device="cuda"), torch.zeros(pad, device="cuda"), torch.zeros(pad, device="cuda")
+    p[:n] = dev(p0)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for it in range(1, 4):
+        grad = torch.randn(n, generator=g) * (10.0 ** (it - 2))
+        O.adam_update(p_ref, grad, m_ref, v_ref, it, lr=1e-4)
+        gd = torch.zeros(pad, device="cuda")
+        gd[:n] = dev(grad) * 4.0                              # grad_scale 0.25 undoes this
+        _lib.check(lib.mmqg_counter_add(step.data_ptr(), 1, ops._stream()))
+        _lib.check(lib.mmqg_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8,
+                                      step.data_ptr(), 0.25, ops._stream()))
+        close(p[:n], p_ref, tol=2e-7, what=f"adam p step {it}")
+        close(m[:n], m_ref, tol=1e-6, what="adam m")
+        close(v[:n], v_ref, tol=1e-6, what="adam v")
+    assert int(step) == 3
+
+
+# ------------------------------------------------------------------------ sequence executors
+@pytest.mark.parametrize("T,B,L,H,In,p", [(5, 3, 3, 16, 12, 0.0), (4, 6, 2, 32, 20, 0.3), (7, 4, 1, 24, 40, 0.0)])
+def test_lstm_sequence_executor_forward_backward(mm, T, B, L, H, In, p):
+    """mmqg_lstm_seq_fwd/bwd (autograd wrapper LSTMSeqFn) vs the oracle's stacked cell loop, with
+    a given initial state and the executor's own dropout masks replayed into the oracle."""
+    _lib, ops = mm
+    from oracle import mmqg_oracle as O
+    g = torch.Generator().manual_seed(T * B + H)
+    params = {}
+    for l in range(L):
+        d = In if l == 0 else H
+        params[f"lstm.weight_ih_l{l}"] = torch.randn(4 * H, d, generator=g) * d ** -0.5
+        params[f"lstm.weight_hh_l{l}"] = torch.randn(4 * H, H, generator=g) * H ** -0.5
+        params[f"lstm.bias_ih_l{l}"] = torch.randn(4 * H, generator=g) * 0.3
+        params[f"lstm.bias_hh_l{l}"] = torch.randn(4 * H, generator=g) * 0.3
+    x = torch.randn(T, B, In, generator=g)
+    h0, c0 = torch.randn(L, B, H, generator=g) * 0.5, torch.randn(L, B, H, generator=g) * 0.5
+    gy, ghT, gcT = torch.randn(T, B, H, generator=g), torch.randn(L, B, H, generator=g), torch.randn(L, B, H, generator=g)
+    seed = 4242
+
+    flat = [dev(params[f"lstm.{n}_l{l}"]).requires_grad_(True) for l in range(L)
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    xd, h0d, c0d = (dev(t).requires_grad_(True) for t in (x, h0, c0))
+    y, hT, cT = ops.lstm_seq(xd, h0d, c0d, flat, p, True, seed)
+    ((y * dev(gy)).sum() + (hT * dev(ghT)).sum() + (cT * dev(gcT)).sum()).backward()
+    # replay the executor's masks: stream id = stream_base + l*T + t, element = b*H + j
+    base = (next(ops._stream_counter) - 1) << 32
+    masks = None
+    if p > 0 and L > 1:
+        masks = [[ops.dropout_mask(B * H, p, seed, base + l * T + t, "cuda").view(B, H).cpu().double()
+                  for l in range(L - 1)] for t in range(T)]
+
+    pd = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    xo, h0o, c0o = (t.double().requires_grad_(True) for t in (x, h0, c0))
+    hid = (h0o, c0o)
+    outs = []
+    for t in range(T):
+        out, hid = O.lstm_stack_step(pd, "lstm.", L, xo[t], hid, None if masks is None else masks[t])
+        outs.append(out)
+    yo = torch.stack(outs)
+    ((yo * gy.double()).sum() + (hid[0] * ghT.double()).sum() + (hid[1] * gcT.double()).sum()).backward()
+    close(y, yo.float(), what="y")
+    close(hT, hid[0].float(), what="hT")
+    close(cT, hid[1].float(), what="cT")
+    close(xd.grad, xo.grad.float(), what="dx")
+    close(h0d.grad, h0o.grad.float(), what="dh0")
+    close(c0d.grad, c0o.grad.float(), what="dc0")
+    i = 0
+    for l in range(L):
+        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            close(flat[i].grad, pd[f"lstm.{n}_l{l}"].grad.float(), what=f"d{n}_l{l}")
+            i += 1

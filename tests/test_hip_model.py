@@ -1,0 +1,319 @@
+"""Model-level parity on the GPU: the drop-in modules driven exactly like the reference drives
+its own (train.py:149-181, one question at a time) and the batched trainer, against the golden
+vectors captured from the reference (tests/golden/*.npz) and against the CPU oracle on seeded
+inputs.  fp32 tolerance 1e-4; greedy token ids bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import clone_params, collate, load_npz, small_cfg, small_params, small_samples, state_from
+from seeded import decoder_spec, lstm_spec, seeded_params, text_spec
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def mm():
+    import mmqg_amd  # noqa: F401
+    from mmqg_amd import _lib
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test on a machine without a ROCm device")
+    _lib.load()
+    from model.decoder import AttnDecoder
+    from model.encoder import AudioVideoEncoder, TextEncoder, VideoConvLstmEncoder
+    from mmqg_amd.trainer import BatchedTrainer
+    return dict(AttnDecoder=AttnDecoder, TextEncoder=TextEncoder, VideoConvLstmEncoder=VideoConvLstmEncoder,
+                AudioVideoEncoder=AudioVideoEncoder, BatchedTrainer=BatchedTrainer)
+
+
+def close(got, want, tol=TOL, what=""):
+    got = torch.as_tensor(got).detach().double().cpu()
+    want = torch.as_tensor(np.asarray(want) if not torch.is_tensor(want) else want).detach().double().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(1.0, float(want.abs().max())) if want.numel() else 1.0
+    err = float((got - want).abs().max()) if want.numel() else 0.0
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def build_small(mm, z, prefix="init", dropout=0.0):
+    c, cfg = small_cfg(z)
+    emb = torch.nn.Embedding(c["V"], c["E"])
+    vid = mm["VideoConvLstmEncoder"](3, 3, 1, c["Dv"], c["flatten"])
+    text = mm["TextEncoder"](c["L"], dropout, c["H"], c["E"], emb, "cuda")
+    dec = mm["AttnDecoder"](c["L"], dropout, c["H"], c["V"], c["E"], c["Dv"], c["Da"], emb, c["Lt"], c["Lav"], "cuda")
+    vid.load_state_dict(state_from(z, f"{prefix}/vid"))
+    text.load_state_dict(state_from(z, f"{prefix}/text"))
+    dec.load_state_dict(state_from(z, f"{prefix}/dec"))
+    assert text.word_embeddings.weight is dec.emb_layer.weight
+    return c, cfg, vid.cuda(), text.cuda(), dec.cuda()
+
+
+def run_question_like_train_py(vid, text_enc, dec, s, c, teacher_forcing=True, max_len=None, stop_at_end=False):
+    """train.py:153-175 (validate: train.py:81-110) around the drop-in modules."""
+    frames, audio, ctx, tgt = (s[k].cuda() for k in ("frames", "audio", "context", "target"))
+    video_emb = vid(frames.unsqueeze(0)).squeeze(1)
+    n_frames = video_emb.shape[0]
+    pad_a = F.pad(audio, (0, 0, 0, c["Lav"] - n_frames))
+    pad_v = F.pad(video_emb, (0, 0, 0, c["Lav"] - n_frames))
+    hid = text_enc.init_state(1)
+    enc_all = torch.zeros(c["Lt"], text_enc.hidden_dim, device="cuda")
+    rows = []
+    for ei in range(len(ctx)):
+        out, hid = text_enc(ctx[ei], hid)
+        rows.append(out[0, 0])
+    enc_all = torch.cat((torch.stack(rows), enc_all[len(ctx):]))       # out-of-place form of train.py:166
+    word = torch.tensor([[c["start_id"]]], device="cuda")
+    loss = 0
+    logits_all, attn_all, ids = [], [], []
+    steps = len(tgt) if max_len is None else max_len
+    for di in range(steps):
+        logits, hid, a_t, a_a, a_v = dec(word, n_frames, torch.tensor([len(ctx)]), pad_a, pad_v, hid, enc_all)
+        logits_all.append(logits[0])
+        attn_all.append(torch.cat((a_t[0], a_a[0], a_v[0])))
+        if di < len(tgt):
+            loss = loss + F.cross_entropy(logits, tgt[di].view(-1))
+        if teacher_forcing:
+            word = tgt[di]
+        else:
+            nxt = torch.argmax(F.softmax(logits, dim=1), dim=1, keepdim=True)
+            ids.append(int(nxt))
+            word = nxt.detach()
+            if stop_at_end and ids[-1] == c["end_id"]:
+                break
+    return dict(loss=loss, logits=torch.stack(logits_all), attn=torch.stack(attn_all), hidden=hid, video_emb=pad_v,
+                enc_all=enc_all, ids=ids)
+
+
+# ------------------------------------------------------------------ drop-in, per token
+def test_dropin_modules_match_reference_forward_and_backward(mm):
+    z = load_npz("small_model.npz")
+    samples = small_samples(z)
+    c, cfg, vid, text, dec = build_small(mm, z)
+    init_vid = {k: v.clone() for k, v in vid.state_dict().items()}
+    vid.train(); text.train(); dec.train()
+    for b, s in enumerate(samples):
+        vid.load_state_dict(init_vid)
+        for m in (vid, text, dec):
+            m.zero_grad()
+        r = run_question_like_train_py(vid, text, dec, s, c)
+        r["loss"].backward()
+        close(r["loss"], z[f"train/{b}/loss"], what="loss")
+        close(r["logits"], z[f"train/{b}/logits"], what="logits")
+        close(r["attn"], z[f"train/{b}/attn"], what="attention weights")
+        close(r["hidden"][0], z[f"train/{b}/h"], what="h")
+        close(r["hidden"][1], z[f"train/{b}/c"], what="c")
+        close(r["video_emb"], z[f"train/{b}/video_emb"], what="video_emb")
+        close(r["enc_all"], z[f"train/{b}/enc_all"], what="enc_all")
+        for name, mod in (("vid", vid), ("text", text), ("dec", dec)):
+            for k, p in mod.named_parameters():
+                close(p.grad, z[f"train/{b}/grad/{name}/{k}"], what=f"grad {name}/{k}")
+
+
+def test_dropin_modules_train_with_torch_adam_like_train_py(mm):
+    """The reference's optimizer setup verbatim (three torch Adam instances, shared embedding in
+    two of them) on the drop-in modules: weights after two iterations match the reference's."""
+    z = load_npz("small_model.npz")
+    samples = small_samples(z)
+    c, cfg, vid, text, dec = build_small(mm, z)
+    vid.train(); text.train(); dec.train()
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-4) for m in (vid, text, dec)]
+    for it, b in enumerate((0, 1)):
+        for o in opts:
+            o.zero_grad()
+        r = run_question_like_train_py(vid, text, dec, samples[b], c)
+        r["loss"].backward()
+        for o in opts:
+            o.step()
+        close(r["loss"], z[f"adam/{it}/loss"], what="loss")
+        for name, mod in (("vid", vid), ("text", text), ("dec", dec)):
+            want = state_from(z, f"adam/{it}/{name}")
+            for k, t in mod.state_dict().items():
+                if not k.endswith("num_batches_tracked"):
+                    close(t, want[k], tol=2e-6, what=f"{name}/{k} after iteration {it}")
+
+
+def test_dropin_eval_greedy_decode_ids_bit_exact(mm):
+    z = load_npz("small_model.npz")
+    samples = small_samples(z)
+    c, cfg, vid, text, dec = build_small(mm, z, prefix="adam/1")
+    vid.eval(); text.eval(); dec.eval()
+    with torch.no_grad():
+        for b, s in enumerate(samples):
+            r = run_question_like_train_py(vid, text, dec, s, c, teacher_forcing=False)
+            close(r["logits"], z[f"eval/{b}/logits"], what="eval logits")
+            close(r["loss"], z[f"eval/{b}/loss"], what="eval loss")
+            assert r["ids"] == z[f"eval/{b}/ids"].tolist()
+            r2 = run_question_like_train_py(vid, text, dec, s, c, teacher_forcing=False, max_len=8, stop_at_end=True)
+            assert r2["ids"] == z[f"eval/{b}/ids_stop"].tolist()
+
+
+def test_default_dims_decoder_text_and_feature_bypass(mm):
+    z = load_npz("default_dims.npz")
+    c = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg/")}
+    dec_sd = seeded_params(decoder_spec(c["V"], c["E"], c["H"], c["L"], c["Lt"], c["Lav"], c["Da"], c["Dv"]), c["seed_dec"])
+    text_sd = seeded_params(text_spec(c["V"], c["E"], c["H"], c["L"]), c["seed_text"])
+    text_sd["word_embeddings.weight"] = dec_sd["emb_layer.weight"]
+    vid_sd = seeded_params(lstm_spec("lstm.", c["feat"], c["Dv"], 1), c["seed_vid"])
+    emb = torch.nn.Embedding(c["V"], c["E"])
+    text = mm["TextEncoder"](c["L"], 0.2, c["H"], c["E"], emb, "cuda")
+    dec = mm["AttnDecoder"](c["L"], 0.2, c["H"], c["V"], c["E"], c["Dv"], c["Da"], emb, c["Lt"], c["Lav"], "cuda")
+    vid = mm["VideoConvLstmEncoder"](3, 3, 1, c["Dv"], c["feat"])
+    dec.load_state_dict(dec_sd); text.load_state_dict(text_sd)
+    vid.load_state_dict(vid_sd, strict=False)
+    text.cuda().eval(); dec.cuda().eval(); vid.cuda().eval()
+    g = torch.Generator().manual_seed(c["seed_in"])
+    feats = torch.randn(c["T"], c["feat"], generator=g)
+    audio = torch.randn(c["T"], c["Da"], generator=g)
+    ctx = torch.randint(3, c["V"], (c["ctx"],), generator=g)
+    words = torch.randint(3, c["V"], (3,), generator=g)
+    with torch.no_grad():
+        video_emb = vid(feats.cuda()).squeeze(1)
+        close(video_emb, z["video_emb"], what="feature-bypass frame LSTM")
+        pad_v = F.pad(video_emb, (0, 0, 0, c["Lav"] - c["T"]))
+        pad_a = F.pad(audio.cuda(), (0, 0, 0, c["Lav"] - c["T"]))
+        hid = text.init_state(1)
+        rows = []
+        for ei in range(c["ctx"]):
+            o, hid = text(ctx[ei].cuda(), hid)
+            rows.append(o[0, 0])
+        close(torch.stack(rows), z["enc_rows"], what="text encoder rows")
+        close(hid[0], z["enc_h"]); close(hid[1], z["enc_c"])
+        enc_all = F.pad(torch.stack(rows), (0, 0, 0, c["Lt"] - c["ctx"]))
+        # the whole context in ONE call gives the same rows (encoder.py:96-98 accepts a sequence)
+        o_seq, hid_seq = text(ctx.cuda().view(1, -1), text.init_state(1))
+        close(o_seq[:, 0], z["enc_rows"], what="text encoder, sequence call")
+        close(hid_seq[0], z["enc_h"])
+        for i in range(3):
+            logits, hid, a_t, a_a, a_v = dec(words[i].cuda(), c["T"], torch.tensor([c["ctx"]]), pad_a, pad_v, hid, enc_all)
+            close(logits, z[f"dec/{i}/logits"], what=f"logits step {i}")
+            close(torch.cat((a_t[0], a_a[0], a_v[0])), z[f"dec/{i}/attn"], what=f"attn step {i}")
+            assert int(torch.argmax(logits)) == int(np.argmax(z[f"dec/{i}/logits"]))
+        close(hid[0], z["dec_h"]); close(hid[1], z["dec_c"])
+
+
+def test_modules_refuse_cpu_tensors(mm):
+    emb = torch.nn.Embedding(20, 8)
+    dec = mm["AttnDecoder"](2, 0.0, 8, 20, 8, 8, 4, emb, 5, 3, "cpu")
+    with pytest.raises(RuntimeError):
+        dec(torch.tensor([[1]]), 2, torch.tensor([3]), torch.zeros(3, 4), torch.zeros(3, 8),
+            (torch.zeros(2, 1, 8), torch.zeros(2, 1, 8)), torch.zeros(5, 8))
+
+
+# --------------------------------------------------------------------- batched trainer
+def _trainer(mm, vid, text, dec, batch, **kw):
+    B, Td = batch["target"].shape
+    return mm["BatchedTrainer"](vid, text, dec, batch_size=B, n_frames=batch["frames"].shape[1],
+                                ctx_len=batch["context"].shape[1], tgt_len=Td, **kw)
+
+
+def test_batched_trainer_ragged_batch_matches_reference_gradients(mm):
+    z = load_npz("small_model.npz")
+    samples = small_samples(z)
+    c, cfg, vid, text, dec = build_small(mm, z)
+    batch = collate(samples)
+    tr = _trainer(mm, vid, text, dec, batch).train()
+    loss = tr.forward_backward(batch)
+    want = np.mean([float(z[f"train/{b}/loss"]) for b in range(3)])
+    close(loss.view(()), np.float32(want), what="batched loss")
+    for name, mod in (("vid", vid), ("text", text), ("dec", dec)):
+        for k, p in mod.named_parameters():
+            ref = np.mean([z[f"train/{b}/grad/{name}/{k}"] for b in range(3)], axis=0)
+            close(p.grad, ref, what=f"batched grad {name}/{k}")
+    # per-question logits / final states inside the batch
+    logits = tr.forward_only(batch, training=True)
+    for b in range(3):
+        n = int(batch["tgt_len"][b])
+        close(logits[b, :n], z[f"train/{b}/logits"], what=f"batched logits q{b}")
+
+
+def test_batched_trainer_two_iterations_match_reference_adam(mm):
+    z = load_npz("small_model.npz")
+    samples = small_samples(z)
+    c, cfg, vid, text, dec = build_small(mm, z)
+    b0, b1 = collate([samples[0]]), collate([samples[1]])
+    # one trainer per shape (buffers are sized at construction); parameters/moments are shared
+    # through the modules only, so run both iterations in one trainer sized for the larger shape
+    big = collate([samples[0], samples[1]])
+    tr = mm["BatchedTrainer"](vid, text, dec, batch_size=1, n_frames=big["frames"].shape[1],
+                              ctx_len=big["context"].shape[1], tgt_len=big["target"].shape[1]).train()
+
+    def padded(one):
+        out = dict(one)
+        out["frames"] = F.pad(one["frames"], (0, 0, 0, 0, 0, 0, 0, tr.Tf - one["frames"].shape[1]))
+        out["audio"] = F.pad(one["audio"], (0, 0, 0, tr.Tf - one["audio"].shape[1]))
+        out["context"] = F.pad(one["context"], (0, tr.Tc - one["context"].shape[1]))
+        out["target"] = F.pad(one["target"], (0, tr.Td - one["target"].shape[1]))
+        return out
+
+    for it, one in enumerate((b0, b1)):
+        loss = tr.step(padded(one))
+        close(loss.view(()), z[f"adam/{it}/loss"], what="loss")
+        for name, mod in (("vid", vid), ("text", text), ("dec", dec)):
+            want = state_from(z, f"adam/{it}/{name}")
+            for k, t in mod.state_dict().items():
+                if not k.endswith("num_batches_tracked"):
+                    close(t, want[k], tol=2e-6, what=f"{name}/{k} after iteration {it}")
+
+
+def _oracle_setup(B, seed, dropout, ragged):
+    from mmqg_amd.synthetic import Workload, synthetic_batch
+    w = Workload("test", batch=B, n_frames=5, frame_dim=40, audio_dim=12, ctx_len=7, tgt_len=6, vocab=90, emb_dim=20,
+                 hidden=32, layers=3, video_hidden=32, text_max_length=11, av_max_length=8, dropout=dropout)
+    return w, synthetic_batch(w, seed=seed, ragged=ragged)
+
+
+@pytest.mark.parametrize("dropout,ragged,mask_mode", [(0.0, False, 0), (0.0, True, 1), (0.25, True, 0)])
+def test_batched_trainer_matches_oracle_on_seeded_inputs(mm, dropout, ragged, mask_mode):
+    """Full step (loss, every gradient, weights after Adam) vs the oracle, including live
+    dropout: the executor's masks are regenerated through mmqg_dropout_mask and fed to the oracle."""
+    from mmqg_amd import ops
+    from mmqg_amd.synthetic import build_models
+    from mmqg_amd.trainer import _DEC_STREAM, _TEXT_STREAM
+    from oracle import mmqg_oracle as O
+    B = 5
+    w, batch = _oracle_setup(B, 3, dropout, ragged)
+    vid, text, dec = build_models(w, "cuda", seed=1)
+    dec.mask_mode = mask_mode
+    tr = _trainer(mm, vid, text, dec, batch, seed=77).train()
+    sd = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in (dec, text, vid)]
+    sd[1]["word_embeddings.weight"] = sd[0]["emb_layer.weight"]
+    cfg = dict(num_layers=w.layers, hidden_dim=w.hidden, text_max_length=w.text_max_length,
+               av_max_length=w.av_max_length, video_hidden_dim=w.video_hidden, start_id=1, end_id=2, mask_mode=mask_mode)
+    drop = None
+    if dropout > 0:
+        H, L = w.hidden, w.layers
+
+        def masks(base, T):
+            return [[ops.dropout_mask(B * H, dropout, 77, base + l * T + t, "cuda", seed_offset=tr.step_dev)
+                     .view(B, H).cpu() for l in range(L - 1)] for t in range(T)]
+        drop = dict(text=masks(_TEXT_STREAM, w.ctx_len), dec=masks(_DEC_STREAM, w.tgt_len))
+    ot = O.OracleTrainer(sd[0], sd[1], sd[2], cfg, lr=1e-4)
+    want_loss, want_logits = ot.step({k: (v.long() if v.dtype == torch.int32 else v) for k, v in batch.items()},
+                                     training=True, drop=drop)
+    grads = {id(t): t.grad.clone() for t in ot.trainable()}
+    loss = tr.forward_backward(batch)
+    close(loss.view(()), np.float32(want_loss), what="loss")
+    for mod, osd in ((dec, sd[0]), (text, sd[1]), (vid, sd[2])):
+        for k, p in mod.named_parameters():
+            if id(osd[k]) in grads:
+                close(p.grad, grads[id(osd[k])], what=f"grad {k}")
+    tr._adam()
+    for mod, osd in ((dec, sd[0]), (text, sd[1]), (vid, sd[2])):
+        for k, p in mod.named_parameters():
+            close(p, osd[k], tol=2e-6, what=f"weight {k} after Adam")
+
+
+def test_graph_replay_equals_eager_steps(mm):
+    from mmqg_amd.synthetic import build_models
+    w, batch = _oracle_setup(4, 9, 0.2, True)
+    results = []
+    for use_graph in (False, True):
+        vid, text, dec = build_models(w, "cuda", seed=2)
+        tr = _trainer(mm, vid, text, dec, batch, seed=5, use_graph=use_graph).train()
+        losses = [float(tr.step(batch)) for _ in range(3)]
+        results.append((losses, tr.flat_p.clone()))
+    assert results[0][0] == pytest.approx(results[1][0], rel=1e-5)
+    assert results[0][0][0] != results[0][0][1]               # fresh dropout masks every step
+    close(results[1][1], results[0][1], tol=1e-5, what="weights after 3 steps")

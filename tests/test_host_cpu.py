@@ -1,0 +1,150 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header
+declares, the ctypes structures match the C layout, config / module host logic."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_mod():
+    import mmqg_amd  # noqa: F401
+    from mmqg_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib
+
+
+def test_library_exports_every_symbol_declared_in_the_header(lib_mod):
+    header = open(os.path.join(ROOT, "include", "mmqg.h")).read()
+    declared = set(re.findall(r"\b(mmqg_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mmqg_stream"}
+    lib = C.CDLL(lib_mod.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/mmqg.h but not exported"
+    assert declared == set(lib_mod.SIGNATURES), (declared ^ set(lib_mod.SIGNATURES))
+    assert lib.mmqg_abi_version() == lib_mod.ABI_VERSION
+
+
+def test_ctypes_structs_match_the_c_layout(lib_mod, tmp_path):
+    """Compile a tiny C program against include/mmqg.h that prints sizeof/offsetof and compare
+    with the ctypes mirror."""
+    fields = {"mmqg_attn_values": ("AttnValues", ["B", "text", "video_stride_b", "mask_mode"]),
+              "mmqg_lstm_seq": ("LstmSeq", ["x", "w_hh", "lens", "seed", "seed_offset", "gates", "y_stride_b"]),
+              "mmqg_lstm_seq_grad": ("LstmSeqGrad", ["dy", "dgates", "lddx", "db_hh", "dc0"]),
+              "mmqg_decoder_seq": ("DecoderSeq", ["values", "xemb", "b_hh", "seed_offset", "scores", "ld_attn", "hdrop"]),
+              "mmqg_decoder_seq_grad": ("DecoderSeqGrad", ["dhtop", "ld_ds", "dxemb", "db_hh", "n_text_rows", "dvideo_stride_b"])}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mmqg.h"', 'int main(void){']
+    for cname, (_, fs) in fields.items():
+        src.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in fs:
+            src.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    src.append("return 0;}")
+    cfile = tmp_path / "layout.c"
+    cfile.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(cfile), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, (pyname, fs) in fields.items():
+        cls = getattr(lib_mod, pyname)
+        assert int(out[cname]) == C.sizeof(cls), cname
+        for f in fs:
+            assert int(out[f"{cname}.{f}"]) == getattr(cls, f).offset, f"{cname}.{f}"
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed(lib_mod):
+    from mmqg_amd import ops
+    from model.decoder import AttnDecoder
+    from model.encoder import TextEncoder
+    emb = torch.nn.Embedding(20, 8)
+    dec = AttnDecoder(2, 0.0, 8, 20, 8, 8, 4, emb, 5, 3, "cpu")
+    text = TextEncoder(2, 0.0, 8, 8, emb, "cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dec(torch.tensor([[1]]), 2, torch.tensor([3]), torch.zeros(3, 4), torch.zeros(3, 8),
+            (torch.zeros(2, 1, 8), torch.zeros(2, 1, 8)), torch.zeros(5, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        text(torch.tensor(1), text.init_state(1))
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd(torch.zeros(2, 2), torch.zeros(2, 2), None)
+
+
+def test_state_dict_keys_and_shapes_follow_the_reference():
+    from model.decoder import AttnDecoder, Decoder
+    from model.encoder import AudioVideoEncoder, TextEncoder
+    emb = torch.nn.Embedding(50, 12)
+    dec = AttnDecoder(3, 0.2, 16, 50, 12, 16, 6, emb, 9, 5, "cpu")
+    keys = list(dec.state_dict().keys())
+    assert keys[:7] == ["emb_layer.weight", "text_attn.weight", "text_attn.bias", "vid_attn.weight", "vid_attn.bias",
+                        "audio_attn.weight", "audio_attn.bias"]
+    assert keys[-2:] == ["out_layer.weight", "out_layer.bias"]
+    assert dec.lstm.weight_ih_l0.shape == (64, 12 + 16 + 6 + 16) and dec.lstm.weight_hh_l2.shape == (64, 16)
+    assert dec.text_attn.weight.shape == (9, 28) and dec.vid_attn.weight.shape == (5, 28)
+    text = TextEncoder(3, 0.2, 16, 12, emb, "cpu")
+    assert list(text.state_dict().keys())[0] == "word_embeddings.weight"
+    assert text.word_embeddings.weight is dec.emb_layer.weight
+    av = AudioVideoEncoder(3, 3, 1, 16, 40)
+    k = set(av.state_dict().keys())
+    assert {"video_enc.conv1.weight", "video_enc.bn4.running_var", "video_enc.bn1.num_batches_tracked",
+            "video_enc.lstm.weight_ih_l0", "video_enc.lstm.bias_hh_l0"} <= k
+    old = Decoder(2, 0.1, 16, 50, 12, 8, emb)
+    assert "lstm.weight_ih_l1" in old.state_dict() and old.lstm.weight_ih_l0.shape == (64, 20)
+    h, c = text.init_state(3)
+    assert h.shape == (3, 3, 16) and float(h.abs().sum()) == 0
+
+
+def test_reference_initialisation_scheme():
+    from model.decoder import AttnDecoder
+    torch.manual_seed(0)
+    emb = torch.nn.Embedding(30, 8)
+    dec = AttnDecoder(2, 0.0, 32, 30, 8, 32, 4, emb, 6, 3, "cpu")
+    w = dec.lstm.weight_hh_l0                       # (128,32) orthogonal columns (decoder.py:110-112)
+    assert torch.allclose(w.t() @ w, torch.eye(32), atol=1e-4)
+    assert 0.5 < float(dec.lstm.bias_ih_l0.std()) < 1.5           # N(0,1) biases (decoder.py:114)
+    bound = (6.0 / (dec.out_layer.weight.shape[0] + dec.out_layer.weight.shape[1])) ** 0.5
+    assert float(dec.out_layer.weight.abs().max()) <= bound + 1e-6    # Xavier-uniform (decoder.py:116)
+
+
+def test_config_keeps_reference_names_and_json_round_trip(tmp_path):
+    from config import Config
+    cfg = Config(make_dirs=False)
+    assert cfg.context_max_lenth == 283 and cfg.av_max_length == 101 and cfg.question_max_length == 21
+    assert cfg.lr == 1e-4 and cfg.audio_emb == 128 and cfg.video_hidden_dim == 512 and cfg.flatten_dim == 1000
+    assert cfg.text_lstm_layers == cfg.dec_lstm_layers == 3 and cfg.text_lstm_dropout == 0.2
+    assert str(cfg.dec_model_path).endswith("results/test/dec_model.pth")
+    old_out = Config.output_path
+    try:
+        Config.output_path = tmp_path
+        cfg.save_config()
+        data = json.load(open(tmp_path / "config.json"))
+        assert data["context_max_lenth"] == 283 and data["optim"] == "adam" and isinstance(data["vocab_file"], str)
+        data["lr"] = 5e-4
+        data["vocab_file"] = "elsewhere/vocab.json"
+        json.dump(data, open(tmp_path / "c2.json", "w"))
+        cfg2 = Config(str(tmp_path / "c2.json"), make_dirs=False)
+        assert cfg2.lr == 5e-4 and str(cfg2.vocab_file) == "elsewhere/vocab.json" and cfg2.optim == "adam"
+    finally:
+        Config.output_path = old_out
+        Config.lr = 1e-4
+        from pathlib import Path
+        Config.vocab_file = Path("data") / "vocab.json"
+
+
+def test_synthetic_batches_are_seeded_and_reserve_special_ids():
+    from mmqg_amd.synthetic import WORKLOADS, Workload, synthetic_batch
+    w = Workload("t", batch=6, n_frames=4, frame_dim=16, audio_dim=8, ctx_len=9, tgt_len=5, vocab=40)
+    a, b = synthetic_batch(w, seed=3, ragged=True), synthetic_batch(w, seed=3, ragged=True)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    for i in range(6):
+        n = int(a["tgt_len"][i])
+        assert int(a["target"][i, n - 1]) == 2 and (a["target"][i, :n - 1] >= 3).all() and (a["target"][i, n:] == 0).all()
+        assert (a["frames"][i, int(a["n_frames"][i]):] == 0).all()
+    assert WORKLOADS["config2"].batch == 64 and WORKLOADS["config2"].text_max_length == 283
+    assert WORKLOADS["config5"].vocab == 50000 and WORKLOADS["config5"].hidden == 1024
