@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: training questions/s (forward + backward + optimizer) of the
+multimodal encoder -> attention decoder step on synthetic tensors, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2]
+
+For N > 1 launch with ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment); every rank trains its own
+shard of the global batch (weak scaling, B questions per GPU) and gradients are all-reduced
+over RCCL.  Rank 0 prints ONE JSON line.
+
+Besides throughput the line carries
+  roofline      the decoder-attention kernel (softmax + context, the HBM-bound kernel BASELINE.json's
+                metric names): algorithmic bytes per launch / average launch duration, measured here
+                with HIP events on the launch stream over back-to-back launches on the step's buffers;
+  roofline_mfma the vocabulary-projection GEMM (fp32 MFMA), same method;
+  cpu_baseline  the CPU oracle (``oracle/``: the reference's batch-1 loop restated, kind "port")
+                timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--batch", type=int, default=0, help="questions per GPU (default: the workload's)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
+    ap.add_argument("--kernel-iters", type=int, default=200, help="launches per kernel-duration measurement")
+    return ap.parse_args()
+
+
+def attention_bytes(w, B):
+    """Algorithmic bytes of ONE attention launch (forward, one decode step, B questions), SURVEY §8d:
+    value rows + query-side i/o; the score matrix is counted by the score GEMM, not here."""
+    vals = 4 * (w.text_max_length * w.hidden + w.av_max_length * w.audio_dim + w.av_max_length * w.video_hidden)
+    S = w.text_max_length + 2 * w.av_max_length
+    io = 4 * (2 * S + (w.hidden + w.audio_dim + w.video_hidden))      # scores in, weights out, context out
+    return B * (vals + io), vals
+
+
+def time_launches(fn, iters):
+    """Average duration of fn() launches enqueued back to back, by HIP events on the current
+    stream (the stream the kernels are launched on)."""
+    for _ in range(5):
+        fn(0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3      # seconds
+
+
+def kernel_rooflines(tr, w, iters):
+    from mmqg_amd import _lib, ops
+    lib, s = _lib.load(), ops._stream()
+    d = tr.d_dec
+    ws = tr.ws
+    B, Td, ldS, Cw = tr.B, tr.Td, tr.ldS, tr.Cw
+    sc, at, cx = ws["scores"], ws["attn"], ws["ctx"]
+
+    def attn(i):
+        t = i % Td
+        _lib.check(lib.mmqg_attn_softmax_context_fwd(C.byref(d.values), sc[t].data_ptr(), ldS, at[t].data_ptr(), ldS,
+                                                     cx[t].data_ptr(), Cw, s))
+    dt = time_launches(attn, iters)
+    nbytes, _ = attention_bytes(w, B)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "attn_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(w.name.split(":")[0], {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roof = {"kernel": "attn_softmax_context_fwd_kernel", "bound": "hbm", "achieved": round(nbytes / dt / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "bytes_per_launch": nbytes, "us_per_launch": round(dt * 1e6, 2)}
+    # vocabulary projection: logits[Td*B, V] = h_top * W_out^T + b
+    R, H, V = Td * B, tr.H, tr.V
+    htop = ws["hs_d"][tr.L - 1, 1:].reshape(R, H)
+    out = tr.dec.out_layer
+    scratch = torch.empty(R, V, device=htop.device)
+
+    def proj(i):
+        ops.gemm(0, 0, R, V, H, htop, H, out.weight, H, scratch, V, bias=out.bias)
+    dtp = time_launches(proj, max(10, iters // 10))
+    flops = 2.0 * R * H * V
+    mfma = {"kernel": "gemm_f32_kernel<128,128,16> (vocab projection fwd)", "bound": "mfma",
+            "achieved": round(flops / dtp / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / dtp / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+            "flops_per_launch": flops, "us_per_launch": round(dtp * 1e6, 2)}
+    return roof, mfma
+
+
+def cpu_baseline(w, budget_s):
+    """The reference's semantics on the host cores: batch-1 loop of zero_grad -> encoders ->
+    per-token decoder with teacher forcing -> summed CE -> backward -> Adam (train.py:149-181),
+    restated by the oracle.  Bounded: one warm-up question, then questions until the budget."""
+    from mmqg_amd.synthetic import build_models, synthetic_batch
+    from oracle import mmqg_oracle as O
+    vid, text, dec = build_models(w, "cpu", seed=0)
+    sd = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in (dec, text, vid)]
+    sd[1]["word_embeddings.weight"] = sd[0]["emb_layer.weight"]
+    cfg = dict(num_layers=w.layers, hidden_dim=w.hidden, text_max_length=w.text_max_length,
+               av_max_length=w.av_max_length, video_hidden_dim=w.video_hidden, start_id=1, end_id=2, mask_mode=0)
+    ot = O.OracleTrainer(sd[0], sd[1], sd[2], cfg)
+    g = torch.Generator().manual_seed(0)
+    H, L, p = w.hidden, w.layers, w.dropout
+
+    def masks(T):
+        keep = 1.0 - p
+        return [[(torch.rand(1, H, generator=g) < keep).float() / keep for _ in range(L - 1)] for _ in range(T)]
+
+    def one(i):
+        b = synthetic_batch(w, seed=100 + i, batch=1)
+        b = {k: (v.long() if v.dtype == torch.int32 else v) for k, v in b.items()}
+        drop = dict(text=masks(w.ctx_len), dec=masks(w.tgt_len)) if p > 0 else None
+        ot.step(b, training=True, drop=drop)
+
+    one(0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(n + 1)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": round(n / el, 4), "unit": "questions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} questions, batch 1, {w.name.split(':')[0]} shapes, fwd+bwd+3xAdam, torch-CPU oracle, "
+                      f"{el:.1f} s after 1 warm-up", "host_cpus": os.cpu_count()}
+
+
+def main():
+    a = parse()
+    import mmqg_amd  # noqa: F401
+    from mmqg_amd.synthetic import WORKLOADS, build_models, synthetic_batch
+    from mmqg_amd.trainer import BatchedTrainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    w = WORKLOADS[a.workload]
+    B = a.batch or w.batch
+    vid, text, dec = build_models(w, dev, seed=0)          # same seed on every rank: identical replicas
+    tr = BatchedTrainer(vid, text, dec, batch_size=B, n_frames=w.n_frames, ctx_len=w.ctx_len, tgt_len=w.tgt_len,
+                        lr=1e-4, seed=1234, use_graph=not a.no_graph).train()
+    batches = [synthetic_batch(w, seed=rank * 1000 + i, batch=B) for i in range(4)]    # each rank its own shard
+    batches = [{k: v.to(dev) for k, v in b.items()} for b in batches]
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        tr.step(batches[i % len(batches)])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = tr.step(batches[i % len(batches)])
+    sync()
+    dt = time.perf_counter() - t0
+    loss_val = float(loss)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    if not (loss_val == loss_val):
+        raise SystemExit("loss is NaN")
+
+    out = {"metric": "training questions/sec (fwd+bwd+optimizer)", "value": round(world * B * a.steps / dt, 2),
+           "unit": "questions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": w.name, "global_batch": world * B, "batch_per_gpu": B, "n_frames": w.n_frames,
+                      "frame_dim": w.frame_dim, "audio_dim": w.audio_dim, "ctx_len": w.ctx_len, "tgt_len": w.tgt_len,
+                      "vocab": w.vocab, "emb_dim": w.emb_dim, "hidden": w.hidden, "layers": w.layers,
+                      "attn_widths": [w.text_max_length, w.av_max_length], "dropout": w.dropout,
+                      "parallelism": f"dp{world}", "hipgraph": not a.no_graph},
+           "final_loss": round(loss_val, 4)}
+    if rank == 0:
+        roof, mfma = kernel_rooflines(tr, w, a.kernel_iters)
+        out["roofline"], out["roofline_mfma"] = roof, mfma
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -128,8 +128,8 @@ int mmqg_reduce_sum(const float* x, int n, float* out, mmqg_stream stream);
  * Adam (torch.optim.Adam defaults, train.py:265-267,179-181) over a flat parameter range.
  * `step` is a device int32 holding the 1-based step number (so a captured graph can be
  * replayed); grads are multiplied by grad_scale first (1/world_size after an all-reduce sum). */
-int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
-                   float b2, float eps, const int32_t* step, float grad_scale, mmqg_stream stream);
+int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1,
+                   double b2, double eps, const int32_t* step, float grad_scale, mmqg_stream stream);
 int mmqg_counter_add(int32_t* counter, int delta, mmqg_stream stream);
 
 /* ------------------------------------------------------------------------------------------

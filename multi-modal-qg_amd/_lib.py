@@ -96,7 +96,7 @@ SIGNATURES = {
     "mmqg_ce_fwd_bwd": [c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i, c_f],
     "mmqg_colsum_add": [c_f, c_i, c_i, c_i, c_f, c_f],
     "mmqg_reduce_sum": [c_f, c_i, c_f, c_f],
-    "mmqg_adam_step": [c_f, c_f, c_f, c_f, c_i64, c_fl, c_fl, c_fl, c_fl, c_f, c_fl, c_f],
+    "mmqg_adam_step": [c_f, c_f, c_f, c_f, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, c_f, c_fl, c_f],
     "mmqg_counter_add": [c_f, c_i, c_f],
     "mmqg_lstm_seq_fwd": [C.POINTER(LstmSeq), c_f],
     "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],

@@ -11,15 +11,16 @@
 namespace {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
-                                                   float b1, float b2, float eps, const int32_t* __restrict__ step,
-                                                   float grad_scale) {
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, double lr,
+                                                   double b1d, double b2d, float eps, const int32_t* __restrict__ step,
+                                                   float grad_scale, float omb1, float omb2) {
     __shared__ float sh[2];
+    const float b1 = (float)b1d, b2 = (float)b2d;
     if (threadIdx.x == 0) {
         const double t = (double)step[0];
-        const double bc1 = 1.0 - pow((double)b1, t);
-        const double bc2 = 1.0 - pow((double)b2, t);
-        sh[0] = (float)((double)lr / bc1);     // step size
+        const double bc1 = 1.0 - pow(b1d, t);
+        const double bc2 = 1.0 - pow(b2d, t);
+        sh[0] = (float)(lr / bc1);     // step size
         sh[1] = (float)sqrt(bc2);              // sqrt of the second-moment correction
     }
     __syncthreads();
@@ -35,8 +36,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float gr = ga[k] * grad_scale;
-                ma[k] = b1 * ma[k] + (1.f - b1) * gr;
-                va[k] = b2 * va[k] + (1.f - b2) * gr * gr;
+                ma[k] = b1 * ma[k] + omb1 * gr;
+                va[k] = b2 * va[k] + omb2 * gr * gr;
                 pa[k] -= step_size * ma[k] / (sqrtf(va[k]) / bc2_sqrt + eps);
             }
             *reinterpret_cast<float4*>(p + i) = pp;
@@ -45,8 +46,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         } else {
             for (int64_t j = i; j < n; ++j) {
                 const float gr = g[j] * grad_scale;
-                const float mj = b1 * m[j] + (1.f - b1) * gr;
-                const float vj = b2 * v[j] + (1.f - b2) * gr * gr;
+                const float mj = b1 * m[j] + omb1 * gr;
+                const float vj = b2 * v[j] + omb2 * gr * gr;
                 m[j] = mj; v[j] = vj;
                 p[j] -= step_size * mj / (sqrtf(vj) / bc2_sqrt + eps);
             }
@@ -60,15 +61,15 @@ __global__ void counter_add_kernel(int32_t* ctr, int delta) { ctr[0] += delta; }
 
 namespace mmqg {
 
-int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+int adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps,
               const int32_t* step, float grad_scale, hipStream_t s) {
     MMQG_REQUIRE(n >= 0, "adam_step: negative length");
     if (n == 0) return 0;
     MMQG_REQUIRE(p && g && m && v && step, "adam_step: null pointer");
     MMQG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adam_step: buffers must be 16-byte aligned");
     const int64_t blocks = std::min<int64_t>(ceil_div64(n, 1024), 2048);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, step,
-                       grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2,
+                       (float)eps, step, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2));
     return check_launch("adam_step");
 }
 

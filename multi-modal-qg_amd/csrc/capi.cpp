@@ -100,7 +100,7 @@ int mmqg_colsum_add(const float* X, int ld, int M, int N, float* out, mmqg_strea
 }
 int mmqg_reduce_sum(const float* x, int n, float* out, mmqg_stream stream) { return reduce_sum(x, n, out, S(stream)); }
 
-int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps,
                    const int32_t* step, float grad_scale, mmqg_stream stream) {
     return adam_step(p, g, m, v, n, lr, b1, b2, eps, step, grad_scale, S(stream));
 }

@@ -71,7 +71,7 @@ int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t s
                      hipStream_t s);
 
 // ---- adam.hip -------------------------------------------------------------------------
-int adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+int adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps,
               const int32_t* step, float grad_scale, hipStream_t s);
 int counter_add(int32_t* ctr, int delta, hipStream_t s);
 

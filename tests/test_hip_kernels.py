@@ -213,12 +213,12 @@ def test_attention_dvalues_over_steps(mm):
     dctx = torch.randn(T, B, Cw, generator=g)
     n_rows = 7
     out = torch.full((n_rows, B, H), 7.0, device="cuda")        # time-major [row][b][H]
-    _lib.check(_lib.load().mmqg_attn_dvalues(T, B, n_rows, H, dev(attn).data_ptr(), B * S, S, 0, dev(dctx).data_ptr(),
+    a_d, d_d = dev(attn), dev(dctx)                               # keep alive: the call only sees raw pointers
+    _lib.check(_lib.load().mmqg_attn_dvalues(T, B, n_rows, H, a_d.data_ptr(), B * S, S, 0, d_d.data_ptr(),
                                              B * Cw, Cw, 0, out.data_ptr(), B * H, H, 0, ops._stream()))
     want = torch.einsum("tbr,tbh->rbh", attn[:, :, :n_rows].double(), dctx[:, :, :H].double())
     close(out, want.float(), what="dvalues text")
     outv = torch.zeros(B, Lav, Dv, device="cuda")
-    a_d, d_d = dev(attn), dev(dctx)
     _lib.check(_lib.load().mmqg_attn_dvalues(T, B, Lav, Dv, a_d.data_ptr(), B * S, S, Lt + Lav, d_d.data_ptr(), B * Cw, Cw,
                                              H + Da, outv.data_ptr(), Dv, Lav * Dv, 0, ops._stream()))
     wantv = torch.einsum("tbr,tbh->brh", attn[:, :, Lt + Lav:].double(), dctx[:, :, H + Da:].double())
@@ -239,9 +239,10 @@ def test_lstm_cell_forward_backward_with_ragged_rows_and_dropout(mm, B, H):
     gates = dev(pre).clone()
     h_out, c_out, h_drop = (torch.empty(B, H, device="cuda") for _ in range(3))
     y = torch.full((B, H + 3), -5.0, device="cuda")
-    _lib.check(lib.mmqg_lstm_cell_fwd(B, H, gates.data_ptr(), 4 * H, dev(h_prev).data_ptr(), dev(c_prev).data_ptr(),
+    hp_d, cp_d, lens_d = dev(h_prev), dev(c_prev), dev(lens)     # keep alive: the calls only see raw pointers
+    _lib.check(lib.mmqg_lstm_cell_fwd(B, H, gates.data_ptr(), 4 * H, hp_d.data_ptr(), cp_d.data_ptr(),
                                       h_out.data_ptr(), c_out.data_ptr(), h_drop.data_ptr(), y.data_ptr(), H + 3,
-                                      dev(lens).data_ptr(), t, p, seed, stream, ops._stream()))
+                                      lens_d.data_ptr(), t, p, seed, stream, ops._stream()))
     mask = ops.dropout_mask(B * H, p, seed, stream, "cuda").view(B, H).cpu()
     active = (lens > t).view(-1, 1)
     # oracle: the cell with identity "weights" (pre-activations given directly)
@@ -266,9 +267,10 @@ def test_lstm_cell_forward_backward_with_ragged_rows_and_dropout(mm, B, H):
     dh_rec = dev(gh).clone()
     dc = dev(gc).clone()
     dgates = torch.empty(B, 4 * H, device="cuda")
-    _lib.check(lib.mmqg_lstm_cell_bwd(B, H, gates.data_ptr(), dev(c_prev).data_ptr(), c_out.data_ptr(), dh_rec.data_ptr(),
-                                      dev(gd).data_ptr(), H, p, seed, stream, dev(gy).data_ptr(), H, dc.data_ptr(),
-                                      dgates.data_ptr(), 4 * H, dev(lens).data_ptr(), t, ops._stream()))
+    gd_d, gy_d = dev(gd), dev(gy)
+    _lib.check(lib.mmqg_lstm_cell_bwd(B, H, gates.data_ptr(), cp_d.data_ptr(), c_out.data_ptr(), dh_rec.data_ptr(),
+                                      gd_d.data_ptr(), H, p, seed, stream, gy_d.data_ptr(), H, dc.data_ptr(),
+                                      dgates.data_ptr(), 4 * H, lens_d.data_ptr(), t, ops._stream()))
     close(dgates, pr.grad.float(), what="dgates")
     close(dc, cp.grad.float(), what="dc_prev")
     # dh_rec holds only the pass-through part (finished rows); active rows get theirs from dgates*W_hh
@@ -327,7 +329,8 @@ def test_colsum_and_reduce_sum(mm):
     close(out, (X.double().sum(0) + 1).float(), what="colsum")
     x = torch.randn(1000, generator=g)
     r = torch.zeros(1, device="cuda")
-    _lib.check(_lib.load().mmqg_reduce_sum(dev(x).data_ptr(), 1000, r.data_ptr(), ops._stream()))
+    x_d = dev(x)
+    _lib.check(_lib.load().mmqg_reduce_sum(x_d.data_ptr(), 1000, r.data_ptr(), ops._stream()))
     close(r, x.double().sum().float().view(1), what="reduce_sum")
 
 

@@ -292,7 +292,7 @@ def test_batched_trainer_matches_oracle_on_seeded_inputs(mm, dropout, ragged, ma
     ot = O.OracleTrainer(sd[0], sd[1], sd[2], cfg, lr=1e-4)
     want_loss, want_logits = ot.step({k: (v.long() if v.dtype == torch.int32 else v) for k, v in batch.items()},
                                      training=True, drop=drop)
-    grads = {id(t): t.grad.clone() for t in ot.trainable()}
+    grads = {id(t): t.grad.clone() for t in ot.trainable() if t.grad is not None}
     loss = tr.forward_backward(batch)
     close(loss.view(()), np.float32(want_loss), what="loss")
     for mod, osd in ((dec, sd[0]), (text, sd[1]), (vid, sd[2])):
