@@ -9,7 +9,8 @@
  *   - the CALLER owns every buffer; pointers are raw device addresses (torch
  *     tensor.data_ptr()), fp32 row-major unless stated, ids int64, lengths int32;
  *   - the library never allocates, frees or synchronises; every function only enqueues
- *     kernels (and memsets) on the hipStream_t passed as `stream`, so autograd ordering on
+ *     kernels on the hipStream_t passed as `stream` (zero fills and copies are kernels too:
+ *     hipMemsetAsync nodes proved racy under hipGraph replay), so autograd ordering on
  *     PyTorch's current stream holds and a call sequence can be captured into a hipGraph;
  *   - return value 0 = enqueued, negative = error; mmqg_last_error() returns the
  *     thread-local message (the Python side raises RuntimeError, as the reference's torch

@@ -19,6 +19,8 @@
 // LDS holds both operands k-major ([k][m] and [k][n], two stages) so an MFMA operand read is
 // one conflict-free ds_read_b32 per lane; global loads are 16 B per lane and are issued for
 // tile t+1 before the MFMAs of tile t, then written to the other LDS stage (one barrier per tile).
+#include <stdlib.h>
+
 #include "mmqg_common.h"
 #include "mmqg_kernels.h"
 
@@ -243,6 +245,18 @@ int launch(const GemmArgs& a, int a_layout, int b_layout, hipStream_t s) {
 
 inline bool can_vec(const float* p, int ld) { return p && mmqg::aligned16(p) && (ld % 4 == 0); }
 
+// zero a [M][N] block with leading dimension ldc (split-K partial sums are added atomically)
+__global__ __launch_bounds__(256) void zero_block_kernel(float* C, int M, int N, int ldc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    C[(i / N) * ldc + (i % N)] = 0.f;
+}
+
+inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 }  // namespace
 
 namespace mmqg {
@@ -277,16 +291,22 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
             while (tiles * split_k < 384 && nk / (split_k * 2) >= 4 && split_k < 16) split_k *= 2;
         }
     }
+    static const int max_split = env_int("MMQG_MAX_SPLITK", 16);      // diagnostics: 1 disables split-K
+    // diagnostics: 1 = hipMemsetAsync (races with neighbouring kernel nodes under hipGraph replay on
+    // ROCm 7.2 / gfx950: NaNs after a few hundred replays; the default is the zeroing kernel above)
+    static const int memset_api = env_int("MMQG_MEMSET_API", 0);
+    if (split_k > max_split) split_k = max_split;
     if (split_k > nk) split_k = nk > 0 ? nk : 1;
     a.split_k = split_k;
     if (split_k > 1 && !beta) {
         // partial products are added atomically, so the destination must start from zero
-        if (ldc == N) {
+        if (memset_api && ldc == N) {
             hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s);
             MMQG_REQUIRE(e == hipSuccess, "gemm_f32: memset failed: %s", hipGetErrorString(e));
         } else {
-            hipError_t e = hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N, M, s);
-            MMQG_REQUIRE(e == hipSuccess, "gemm_f32: memset2d failed: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(zero_block_kernel, dim3((unsigned)mmqg::ceil_div64((int64_t)M * N, 256)), dim3(256), 0, s,
+                               C, M, N, ldc);
+            MMQG_TRY(mmqg::check_launch("gemm_f32 zero"));
         }
     }
     if (small) return launch<64, 64, 32>(a, a_layout, b_layout, s);

@@ -93,6 +93,12 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
     if (i < n) y[i] += alpha * x[i];
 }
 
+__global__ __launch_bounds__(256) void fill_copy_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                        int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src ? src[i] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, int64_t dst_stride,
                                                        const float* __restrict__ src, int64_t src_stride, int rows,
                                                        int cols) {
@@ -141,6 +147,16 @@ int axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, y, x, alpha, n);
     return check_launch("axpy");
+}
+
+// dst[0:n] = src ? src[0:n] : 0.  Own kernel instead of hipMemsetAsync / hipMemcpyAsync: memset nodes
+// captured into a hipGraph were observed (ROCm 7.2, gfx950) to race with neighbouring kernel nodes.
+int copy_or_zero_f32(float* dst, const float* src, int64_t n, hipStream_t s) {
+    MMQG_REQUIRE(n >= 0 && dst, "copy_or_zero_f32: bad arguments");
+    if (n == 0) return 0;
+    const int64_t blocks = std::min<int64_t>(ceil_div64(n, 256), 2048);
+    hipLaunchKernelGGL(fill_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, n);
+    return check_launch("copy_or_zero_f32");
 }
 
 int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int rows, int cols,

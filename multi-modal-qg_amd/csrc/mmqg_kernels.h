@@ -66,6 +66,7 @@ int ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* 
                float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, hipStream_t s);
 int colsum_add(const float* X, int ld, int M, int N, float* out, hipStream_t s);
 int reduce_sum(const float* x, int n, float* out, hipStream_t s);
+int copy_or_zero_f32(float* dst, const float* src, int64_t n, hipStream_t s);
 int axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s);
 int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int rows, int cols,
                      hipStream_t s);

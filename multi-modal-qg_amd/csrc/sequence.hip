@@ -18,10 +18,7 @@ namespace {
 using namespace mmqg;
 
 int copy_or_zero(float* dst, const float* src, size_t n, hipStream_t s) {
-    hipError_t e = src ? hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s)
-                       : hipMemsetAsync(dst, 0, n * sizeof(float), s);
-    MMQG_REQUIRE(e == hipSuccess, "sequence: state init failed: %s", hipGetErrorString(e));
-    return 0;
+    return copy_or_zero_f32(dst, src, (int64_t)n, s);
 }
 
 int check_lstm(const mmqg_lstm_seq& d, const char* who) {
