@@ -1,0 +1,71 @@
+"""Data parallelism for the batched step: one process per GPU, the global batch sharded by
+question (every recurrence and the per-question BatchNorm statistics stay inside one sample, so
+ranks never exchange activations), ONE exchange per iteration: an all-reduce (sum) of the flat
+fp32 gradient buffer over RCCL/xGMI, issued in two buckets so the first overlaps the rest of
+backward.  The 1/world_size scale is folded into the fused Adam kernel (``grad_scale``).
+
+The reference has no distributed code at all; this module is new.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
+    """Rank's contiguous slice of a global batch (dim 0 of every tensor is the question index)."""
+    B = next(iter(batch.values())).shape[0]
+    if B % world:
+        raise ValueError(f"global batch {B} is not divisible by world size {world}")
+    per = B // world
+    return {k: v[rank * per:(rank + 1) * per] for k, v in batch.items()}
+
+
+class GradReducer:
+    """All-reduce of a flat gradient buffer in named buckets.
+
+    ``segments`` maps a name to a [start, end) element range of ``flat_g``; ``order`` lists the
+    buckets in the order their gradients become final during backward.  ``reduce(name)`` starts
+    the bucket's all-reduce asynchronously (RCCL runs it on its own stream once the producer
+    stream reaches this point); ``finish()`` makes the current stream wait for all of them.
+    Works on any device / backend, which is how the world_size-2 gloo tests exercise it.
+    """
+
+    def __init__(self, flat_g: torch.Tensor, buckets: Sequence[Tuple[str, int, int]], group=None):
+        self.flat_g = flat_g
+        self.buckets = {name: (a, b) for name, a, b in buckets}
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._pending: List = []
+
+    def reduce(self, name: str) -> None:
+        if self.world == 1:
+            return
+        a, b = self.buckets[name]
+        if b > a:
+            self._pending.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+
+def trainer_buckets(segments: Dict[str, Tuple[int, int]], n_params: int) -> List[Tuple[str, int, int]]:
+    """Two buckets from the trainer's flat layout (dec | text | vid | emb): the decoder's
+    gradients are final after the decoder backward, everything else (text encoder, frame
+    encoder, shared embedding) only after the encoders' backward."""
+    d0, d1 = segments["dec"]
+    return [("dec", d0, d1), ("rest", d1, n_params)]
+
+
+def broadcast_parameters(flat_p: torch.Tensor, group=None, src: int = 0) -> None:
+    """Initial replica sync (rank ``src``'s parameters everywhere)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_p, src=src, group=group)

@@ -29,6 +29,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import K_MAJOR, MN_MAJOR, check, ptr
+from .distributed import GradReducer, broadcast_parameters, trainer_buckets
 
 _TEXT_STREAM = 1 << 40
 _DEC_STREAM = 2 << 40
@@ -81,6 +82,9 @@ class BatchedTrainer:
         self._describe()
         self.use_graph = use_graph
         self._graph = None
+        self.reducer = GradReducer(self.flat_g, trainer_buckets(self.segments, self.n_params), self.pg)
+        if self.world > 1:
+            broadcast_parameters(self.flat_p, self.pg)
 
     # ------------------------------------------------------------------ parameter layout
     def _flatten_parameters(self):
@@ -228,8 +232,6 @@ class BatchedTrainer:
         dec = self.dec
         dd.w_attn, dd.b_attn = dec.text_attn.weight.data_ptr(), dec.text_attn.bias.data_ptr()
         self._lstm_ptrs(dd, dec.lstm.flat(), gd)
-        top = L - 1
-        dd.h0 = w["hs_t"].data_ptr()      # patched per layer below: encoder final states
         dd.lens = w["tgt_len"].data_ptr()
         dd.dropout_p, dd.seed, dd.stream_base = self.drop_dec, self.seed, _DEC_STREAM
         dd.seed_offset = self.step_dev.data_ptr()
@@ -247,7 +249,6 @@ class BatchedTrainer:
         gd.n_video_rows, gd.dvideo = self.Tf, w["dvideo"].data_ptr()
         gd.dvideo_stride_row, gd.dvideo_stride_b = B * self.Hv, self.Hv
         self.d_dec, self.g_dec = dd, gd
-        del top
 
     # ------------------------------------------------------------------------------ modes
     def train(self, mode: bool = True):
@@ -311,7 +312,20 @@ class BatchedTrainer:
         out = self.dec.out_layer
         ops.gemm(K_MAJOR, K_MAJOR, self.Td * B, V, H, htop, H, out.weight, H, w["logits"], V, bias=out.bias)
 
-    def _loss_and_backward(self, feats_grad_sink=None):
+    def _loss_and_backward(self, part: str = "all"):
+        """part: 'all', or 'dec' (loss + vocabulary projection + decoder backward) / 'rest'
+        (text + frame encoder backward) when the step is split so the decoder bucket's
+        all-reduce overlaps the encoders' backward."""
+        if part in ("all", "dec"):
+            self._backward_decoder()
+            if self.grad_hook:
+                self.grad_hook(self, "dec")
+        if part in ("all", "rest"):
+            self._backward_encoders()
+            if self.grad_hook:
+                self.grad_hook(self, "rest")
+
+    def _backward_decoder(self):
         lib, s, w = _lib.load(), ops._stream(), self.ws
         L, B, H, V, E = self.L, self.B, self.H, self.V, self.E
         R = self.Td * B
@@ -328,13 +342,13 @@ class BatchedTrainer:
         check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s), "decoder_seq_bwd")
         demb = self.dec.emb_layer.weight.grad
         ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
-        if self.grad_hook:
-            self.grad_hook(self, "dec")
+
+    def _backward_encoders(self):
+        lib, s, w, E = _lib.load(), ops._stream(), self.ws, self.E
+        demb = self.dec.emb_layer.weight.grad
         check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text)")
         ops.embedding_bwd(w["dxemb_c"].view(-1, E), w["ids_c"], demb)
         check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s), "lstm_seq_bwd(frames)")
-        if self.grad_hook:
-            self.grad_hook(self, "rest")
 
     def _adam(self):
         lib, s = _lib.load(), ops._stream()
@@ -351,7 +365,9 @@ class BatchedTrainer:
 
     def _allreduce(self):
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat_g, group=self.pg)
+            self.reducer.reduce("dec")
+            self.reducer.reduce("rest")
+            self.reducer.finish()
 
     def forward_backward(self, batch: Optional[dict] = None):
         """zero_grad + forward + loss + backward for the batch already loaded (or ``batch``).
@@ -365,7 +381,9 @@ class BatchedTrainer:
                 feats = self.video.cnn_features(raw, self.ws["n_frames"]).transpose(0, 1).contiguous()
             self.ws["feats"].copy_(feats.detach())
         self._forward(self.training)
-        self._loss_and_backward()
+        self._loss_and_backward("dec")
+        self.reducer.reduce("dec")                 # overlaps the encoders' backward (no-op on 1 GPU)
+        self._loss_and_backward("rest")
         if feats is not None:
             feats.backward(self.ws["dfeats"])
         return self.ws["loss"]
@@ -375,32 +393,43 @@ class BatchedTrainer:
         if self.use_graph and batch is not None and batch["frames"].dim() != 5:
             return self._graph_step(batch)
         loss = self.forward_backward(batch)
-        self._allreduce()
+        self.reducer.reduce("rest")
+        self.reducer.finish()
         self._adam()
         return loss
 
     # ------------------------------------------------------------------------ hipGraph
-    def _graph_body(self):
-        self.flat_g.zero_()
-        self._forward(True)
-        self._loss_and_backward()
+    def _graph_body(self, part: str):
+        if part == "dec":
+            self.flat_g.zero_()
+            self._forward(True)
+        self._loss_and_backward(part)
 
     def _graph_step(self, batch):
         self.load_batch(batch)
         if self._graph is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):      # warm-up outside capture (lazy module loads, RCCL init)
-                self._graph_body()
+            with torch.cuda.stream(side):      # warm-up outside capture (lazy code-object loads)
+                self._graph_body("dec")
+                self._graph_body("rest")
             torch.cuda.current_stream().wait_stream(side)
+            # three graphs: [zero, forward, loss, decoder backward] | [encoder backward] | [Adam];
+            # the gradient all-reduces sit between them (RCCL is not captured)
             self._graph = torch.cuda.CUDAGraph()
+            self._graph_rest = torch.cuda.CUDAGraph()
             self._graph_adam = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._graph_body()
-            with torch.cuda.graph(self._graph_adam):
+                self._graph_body("dec")
+            with torch.cuda.graph(self._graph_rest, pool=self._graph.pool()):
+                self._graph_body("rest")
+            with torch.cuda.graph(self._graph_adam, pool=self._graph.pool()):
                 self._adam()
         self._graph.replay()
-        self._allreduce()
+        self.reducer.reduce("dec")
+        self._graph_rest.replay()
+        self.reducer.reduce("rest")
+        self.reducer.finish()
         self._graph_adam.replay()
         return self.ws["loss"]
 

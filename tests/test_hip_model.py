@@ -317,3 +317,60 @@ def test_graph_replay_equals_eager_steps(mm):
     assert results[0][0] == pytest.approx(results[1][0], rel=1e-5)
     assert results[0][0][0] != results[0][0][1]               # fresh dropout masks every step
     close(results[1][1], results[0][1], tol=1e-5, what="weights after 3 steps")
+
+
+# ------------------------------------------------------------------ data parallel on the GPU
+def _dp_worker(rank, world, port, use_graph, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    # gloo with device tensors: both ranks share the one GPU of the test box (RCCL refuses two
+    # ranks on one device); the trainer's bucketed all-reduce path is the same
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mmqg_amd  # noqa: F401
+    from mmqg_amd.distributed import shard_batch
+    from mmqg_amd.synthetic import build_models
+    from mmqg_amd.trainer import BatchedTrainer
+    w, full = _oracle_setup(4, 21, 0.0, True)
+    vid, text, dec = build_models(w, "cuda", seed=3)
+    shard = shard_batch(full, rank, world)
+    tr = BatchedTrainer(vid, text, dec, batch_size=2, n_frames=w.n_frames, ctx_len=w.ctx_len, tgt_len=w.tgt_len,
+                        use_graph=use_graph).train()
+    for _ in range(2):
+        tr.step(shard)
+    torch.cuda.synchronize()
+    q.put((rank, tr.flat_p.cpu().numpy()))      # by value: the worker may exit before the parent reads
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_rank_data_parallel_step_equals_single_rank_full_batch(mm, use_graph):
+    import socket
+    import torch.multiprocessing as mp
+    from mmqg_amd.synthetic import build_models
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = {k: torch.from_numpy(v) for k, v in res.items()}
+    assert torch.equal(res[0], res[1]), "replicas diverged"
+    w, full = _oracle_setup(4, 21, 0.0, True)
+    vid, text, dec = build_models(w, "cuda", seed=3)
+    tr = _trainer(mm, vid, text, dec, full).train()
+    for _ in range(2):
+        tr.step(full)
+    close(res[0], tr.flat_p, tol=2e-6, what="2-rank DP weights vs single-rank full batch")
