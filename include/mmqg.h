@@ -132,6 +132,10 @@ int mmqg_reduce_sum(const float* x, int n, float* out, mmqg_stream stream);
 int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1,
                    double b2, double eps, const int32_t* step, float grad_scale, mmqg_stream stream);
 int mmqg_counter_add(int32_t* counter, int delta, mmqg_stream stream);
+/* dst[c][r] = src[r][c]: used to keep k-major (transposed) copies of the recurrent weights for
+ * the backward time loops; refresh after every optimizer step. */
+int mmqg_transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst,
+                       mmqg_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole-sequence executors: one call enqueues every kernel of a time loop.
@@ -147,6 +151,8 @@ typedef struct {
     const float* w_hh[MMQG_MAX_LAYERS];             /* [4H][H] */
     const float* b_ih[MMQG_MAX_LAYERS];
     const float* b_hh[MMQG_MAX_LAYERS];
+    const float* w_hhT[MMQG_MAX_LAYERS];            /* optional [H][4H] transposed copies: enable the
+                                                       fused one-launch-per-layer-step backward */
     const float* h0; const float* c0;               /* [L][B][H] or NULL = zeros */
     const int32_t* lens;                            /* [B] or NULL */
     float dropout_p; int32_t training; uint64_t seed; uint64_t stream_base;
@@ -184,6 +190,11 @@ typedef struct {
     const float* w_attn; const float* b_attn;       /* [Lt+2Lav][E+H], [Lt+2Lav] */
     const float* w_ih[MMQG_MAX_LAYERS]; const float* w_hh[MMQG_MAX_LAYERS];
     const float* b_ih[MMQG_MAX_LAYERS]; const float* b_hh[MMQG_MAX_LAYERS];
+    /* optional transposed copies (all or none): w_hhT[l] [H][4H]; w_ihT[l] [H][4H] for l >= 1;
+     * w_ih0cT [H+Da+Dv][4H] = (W_ih0[:, E:])^T; w_attn_hT [H][ld_attn] = (W_attn[:, E:])^T, columns
+     * past Lt+2Lav zero.  With them the backward time loop is one fused launch per layer-step. */
+    const float* w_hhT[MMQG_MAX_LAYERS]; const float* w_ihT[MMQG_MAX_LAYERS];
+    const float* w_ih0cT; const float* w_attn_hT;
     const float* h0; const float* c0;               /* [L][B][H] */
     const int32_t* lens;                            /* [B] target lengths or NULL */
     float dropout_p; int32_t training; uint64_t seed; uint64_t stream_base;

@@ -39,7 +39,7 @@ _PTRS = c_f * MAX_LAYERS
 class LstmSeq(C.Structure):
     _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("In", C.c_int32),
                 ("x", c_f), ("ldx", C.c_int32),
-                ("w_ih", _PTRS), ("w_hh", _PTRS), ("b_ih", _PTRS), ("b_hh", _PTRS),
+                ("w_ih", _PTRS), ("w_hh", _PTRS), ("b_ih", _PTRS), ("b_hh", _PTRS), ("w_hhT", _PTRS),
                 ("h0", c_f), ("c0", c_f), ("lens", c_f),
                 ("dropout_p", c_fl), ("training", C.c_int32), ("seed", c_u64), ("stream_base", c_u64),
                 ("seed_offset", c_f),
@@ -61,6 +61,7 @@ class DecoderSeq(C.Structure):
                 ("values", AttnValues),
                 ("xemb", c_f), ("w_attn", c_f), ("b_attn", c_f),
                 ("w_ih", _PTRS), ("w_hh", _PTRS), ("b_ih", _PTRS), ("b_hh", _PTRS),
+                ("w_hhT", _PTRS), ("w_ihT", _PTRS), ("w_ih0cT", c_f), ("w_attn_hT", c_f),
                 ("h0", c_f), ("c0", c_f), ("lens", c_f),
                 ("dropout_p", c_fl), ("training", C.c_int32), ("seed", c_u64), ("stream_base", c_u64),
                 ("seed_offset", c_f),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "mmqg_reduce_sum": [c_f, c_i, c_f, c_f],
     "mmqg_adam_step": [c_f, c_f, c_f, c_f, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, c_f, c_fl, c_f],
     "mmqg_counter_add": [c_f, c_i, c_f],
+    "mmqg_transpose_f32": [c_f, c_i, c_i, c_i, c_f, c_i, c_f],
     "mmqg_lstm_seq_fwd": [C.POINTER(LstmSeq), c_f],
     "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
     "mmqg_decoder_seq_fwd": [C.POINTER(DecoderSeq), c_f],

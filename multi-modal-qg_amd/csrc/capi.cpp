@@ -105,6 +105,9 @@ int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doub
     return adam_step(p, g, m, v, n, lr, b1, b2, eps, step, grad_scale, S(stream));
 }
 int mmqg_counter_add(int32_t* counter, int delta, mmqg_stream stream) { return counter_add(counter, delta, S(stream)); }
+int mmqg_transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, mmqg_stream stream) {
+    return transpose_f32(src, ld_src, rows, cols, dst, ld_dst, S(stream));
+}
 
 int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream) {
     MMQG_REQUIRE(d, "mmqg_lstm_seq_fwd: null descriptor");

@@ -47,6 +47,23 @@ int lstm_cell_bwd(const CellBwd& a, hipStream_t s);
 int dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t stream_id, const int32_t* seed_off,
                  hipStream_t s);
 
+// ---- skinny.hip: batch-sized products fused with the step's pointwise epilogue ---------
+struct SkinnyPair {
+    const float* A; int lda;      // [M][K] k-major
+    const float* B; int ldb;      // [N][K] k-major
+    int K;
+    int masked;                   // backward only: product goes through the layer's dropout mask
+};
+bool skinny_usable(const SkinnyPair* pairs, int npairs);
+int skinny_plain(int M, int N, const SkinnyPair* pairs, int npairs, const float* bias, int beta, float* C, int ldc,
+                 hipStream_t s);
+// gates (+= if gates_has_pre) sum of pairs + bias1 + bias2, then the cell update of CellFwd
+int skinny_cell_fwd(const SkinnyPair* pairs, int npairs, int gates_has_pre, const float* bias1, const float* bias2,
+                    const CellFwd& f, hipStream_t s);
+// dh(t) = sum of pairs + carry (f.dh_rec) [+ above, extra], then the cell backward of CellBwd
+int skinny_cell_bwd(const SkinnyPair* pairs, int npairs, const CellBwd& f, hipStream_t s);
+int transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s);
+
 // ---- attention.hip --------------------------------------------------------------------
 int attn_softmax_context_fwd(const mmqg_attn_values& v, const float* scores, int ld_s, float* attn, int ld_a,
                              float* ctx, int ld_c, hipStream_t s);

@@ -8,6 +8,8 @@
 // layer-0 gates, every weight gradient (dW = dGates^T * X over all steps at once) and the
 // gradient of the value tensors.  The loop itself keeps only h*W_hh^T (+ the attention
 // context product in the decoder), the cell update and the attention kernels.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "mmqg_common.h"
@@ -36,6 +38,12 @@ int check_lstm(const mmqg_lstm_seq& d, const char* who) {
 
 inline bool lstm_drop(const mmqg_lstm_seq& d) { return d.training && d.dropout_p > 0.f && d.L > 1; }
 
+// MMQG_NO_FUSE=1 keeps the round-1 path (tiled GEMM + separate cell kernels) for A/B comparisons
+inline bool g_no_fuse() {
+    static const bool v = [] { const char* e = getenv("MMQG_NO_FUSE"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 }  // namespace
 
 namespace mmqg {
@@ -59,9 +67,12 @@ int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s) {
         // all input products of the layer at once: gates[t] = X[t]*W_ih^T + b_ih + b_hh
         MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, 4 * H, in, X, ldx, d.w_ih[l], in, nullptr, 0, nullptr, 0, 0,
                           d.b_ih[l], d.b_hh[l], 0, gates_l, 4 * H, -1, s));
+        const SkinnyPair probe{hs_l, H, d.w_hh[l], H, H, 0};
+        const bool fused = (H % 4 == 0) && skinny_usable(&probe, 1) && !g_no_fuse();
         for (int t = 0; t < T; ++t) {
-            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, 4 * H, H, hs_l + t * BH, H, d.w_hh[l], H, nullptr, 0,
-                              nullptr, 0, 0, nullptr, nullptr, 1, gates_l + t * G, 4 * H, -1, s));
+            if (!fused)
+                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, 4 * H, H, hs_l + t * BH, H, d.w_hh[l], H, nullptr, 0,
+                                  nullptr, 0, 0, nullptr, nullptr, 1, gates_l + t * G, 4 * H, -1, s));
             CellFwd c{};
             c.B = B; c.H = H; c.gates = gates_l + t * G; c.ld_g = 4 * H;
             c.h_prev = hs_l + t * BH; c.c_prev = cs_l + t * BH;
@@ -71,7 +82,13 @@ int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s) {
             c.y_stride_b = d.y_stride_b;
             c.lens = d.lens; c.t = t;
             c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
-            MMQG_TRY(lstm_cell_fwd(c, s));
+            if (fused) {
+                // one launch: gates[t] (hoisted X*W_ih^T + biases) += h(t-1)*W_hh^T, then the cell update
+                const SkinnyPair pr{hs_l + t * BH, H, d.w_hh[l], H, H, 0};
+                MMQG_TRY(skinny_cell_fwd(&pr, 1, 1, nullptr, nullptr, c, s));
+            } else {
+                MMQG_TRY(lstm_cell_fwd(c, s));
+            }
         }
     }
     return 0;
@@ -93,6 +110,8 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
         float* dg_l = g.dgates + (int64_t)l * T * G;
         MMQG_TRY(copy_or_zero(g.dh, g.dhT ? g.dhT + l * BH : nullptr, (size_t)BH, s));
         MMQG_TRY(copy_or_zero(g.dc, g.dcT ? g.dcT + l * BH : nullptr, (size_t)BH, s));
+        const SkinnyPair probe{dg_l, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+        const bool fused = d.w_hhT[l] && skinny_usable(&probe, 1) && !g_no_fuse();
         for (int t = T - 1; t >= 0; --t) {
             CellBwd c{};
             c.B = B; c.H = H; c.gates_act = gates_l + t * G;
@@ -106,10 +125,20 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
             }
             c.dc = g.dc; c.dgates = dg_l + t * G; c.ld_dg = 4 * H;
             c.lens = d.lens; c.t = t;
-            MMQG_TRY(lstm_cell_bwd(c, s));
-            // dh(t-1) += dgates(t) * W_hh
-            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, 4 * H, dg_l + t * G, 4 * H, d.w_hh[l], H, nullptr, 0,
-                              nullptr, 0, 0, nullptr, nullptr, 1, g.dh, H, -1, s));
+            if (fused && t < T - 1) {
+                // one launch: dh(t) = dgates(t+1) * W_hh + carried/extra gradients, then the cell backward
+                const SkinnyPair pr{dg_l + (t + 1) * G, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+                MMQG_TRY(skinny_cell_bwd(&pr, 1, c, s));
+            } else {
+                MMQG_TRY(lstm_cell_bwd(c, s));
+            }
+            if (!fused)   // dh(t-1) += dgates(t) * W_hh
+                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, 4 * H, dg_l + t * G, 4 * H, d.w_hh[l], H, nullptr, 0,
+                                  nullptr, 0, 0, nullptr, nullptr, 1, g.dh, H, -1, s));
+        }
+        if (fused && (g.dh0 != nullptr)) {   // gradient of the initial state: carry + dgates(0) * W_hh
+            const SkinnyPair pr{dg_l, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+            MMQG_TRY(skinny_plain(B, H, &pr, 1, nullptr, 1, g.dh, H, s));
         }
         if (g.dh0) MMQG_TRY(copy_or_zero(g.dh0 + l * BH, g.dh, (size_t)BH, s));
         if (g.dc0) MMQG_TRY(copy_or_zero(g.dc0 + l * BH, g.dc, (size_t)BH, s));
@@ -178,22 +207,35 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
         float* at = d.attn + (int64_t)t * B * ldS;
         float* cx = d.ctx + (int64_t)t * B * C;
         // scores += h_top(t-1) * W_attn[:, E:]^T     (decoder.py:78,84,92: query = [emb | h_top])
-        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, S, H, htop_base + t * BH, H, d.w_attn + E, Q, nullptr, 0,
-                          nullptr, 0, 0, nullptr, nullptr, 1, sc, ldS, -1, s));
+        const SkinnyPair spr{htop_base + t * BH, H, d.w_attn + E, Q, H, 0};
+        if (!g_no_fuse() && skinny_usable(&spr, 1))
+            MMQG_TRY(skinny_plain(B, S, &spr, 1, nullptr, 1, sc, ldS, s));
+        else
+            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, S, H, htop_base + t * BH, H, d.w_attn + E, Q, nullptr, 0,
+                              nullptr, 0, 0, nullptr, nullptr, 1, sc, ldS, -1, s));
         MMQG_TRY(attn_softmax_context_fwd(v, sc, ldS, at, ldS, cx, C, s));
         for (int l = 0; l < L; ++l) {
             float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
             float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
             float* gates = d.gates + (int64_t)l * T * G + t * G;
+            SkinnyPair prs[2];
             if (l == 0) {
-                // gates0 += ctx * W_ih0[:, E:]^T + h0 * W_hh0^T
-                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, 4 * H, C, cx, C, d.w_ih[0] + E, In0, hs_l + t * BH, H,
-                                  d.w_hh[0], H, H, nullptr, nullptr, 1, gates, 4 * H, -1, s));
+                prs[0] = SkinnyPair{cx, C, d.w_ih[0] + E, In0, C, 0};
+                prs[1] = SkinnyPair{hs_l + t * BH, H, d.w_hh[0], H, H, 0};
             } else {
                 const float* xin = drop ? d.hdrop + (int64_t)(l - 1) * T * BH + t * BH
                                         : d.hs + (int64_t)(l - 1) * (T + 1) * BH + (t + 1) * BH;
-                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, 4 * H, H, xin, H, d.w_ih[l], H, hs_l + t * BH, H,
-                                  d.w_hh[l], H, H, d.b_ih[l], d.b_hh[l], 0, gates, 4 * H, -1, s));
+                prs[0] = SkinnyPair{xin, H, d.w_ih[l], H, H, 0};
+                prs[1] = SkinnyPair{hs_l + t * BH, H, d.w_hh[l], H, H, 0};
+            }
+            const bool fused = (H % 4 == 0) && skinny_usable(prs, 2) && !g_no_fuse();
+            if (!fused) {
+                if (l == 0)   // gates0 += ctx * W_ih0[:, E:]^T + h0 * W_hh0^T
+                    MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, 4 * H, C, cx, C, d.w_ih[0] + E, In0, hs_l + t * BH, H,
+                                      d.w_hh[0], H, H, nullptr, nullptr, 1, gates, 4 * H, -1, s));
+                else
+                    MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, 4 * H, H, prs[0].A, H, d.w_ih[l], H, hs_l + t * BH, H,
+                                      d.w_hh[l], H, H, d.b_ih[l], d.b_hh[l], 0, gates, 4 * H, -1, s));
             }
             CellFwd c{};
             c.B = B; c.H = H; c.gates = gates; c.ld_g = 4 * H;
@@ -202,7 +244,13 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
             c.h_drop = (drop && l < L - 1) ? d.hdrop + (int64_t)l * T * BH + t * BH : nullptr;
             c.lens = d.lens; c.t = t;
             c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
-            MMQG_TRY(lstm_cell_fwd(c, s));
+            if (fused) {
+                // layer 0: the hoisted emb part + biases already sit in gates; layers > 0 start from the biases
+                if (l == 0) MMQG_TRY(skinny_cell_fwd(prs, 2, 1, nullptr, nullptr, c, s));
+                else MMQG_TRY(skinny_cell_fwd(prs, 2, 0, d.b_ih[l], d.b_hh[l], c, s));
+            } else {
+                MMQG_TRY(lstm_cell_fwd(c, s));
+            }
         }
     }
     return 0;
@@ -221,9 +269,23 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
     const bool drop = d.training && d.dropout_p > 0.f && L > 1;
     MMQG_TRY(copy_or_zero(g.dh, nullptr, (size_t)L * BH, s));
     MMQG_TRY(copy_or_zero(g.dc, nullptr, (size_t)L * BH, s));
+    // fused backward: possible when k-major (transposed) copies of every recurrent weight are given
+    bool fusedb = !g_no_fuse() && d.w_ih0cT && d.w_attn_hT && (ldS % 4 == 0) && (ldD % 4 == 0);
+    for (int l = 0; l < L && fusedb; ++l) {
+        const SkinnyPair a{g.dgates, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+        fusedb = d.w_hhT[l] && skinny_usable(&a, 1);
+        if (fusedb && l > 0) {
+            const SkinnyPair b{g.dgates, 4 * H, d.w_ihT[l], 4 * H, 4 * H, 1};
+            fusedb = d.w_ihT[l] && skinny_usable(&b, 1);
+        }
+    }
+    if (fusedb) {
+        const SkinnyPair a{g.dgates, 4 * H, d.w_ih0cT, 4 * H, 4 * H, 0};
+        const SkinnyPair b{g.dscores, ldD, d.w_attn_hT, ldS, ldS, 0};
+        fusedb = skinny_usable(&a, 1) && skinny_usable(&b, 1) && (ldD >= ldS);
+    }
     for (int t = T - 1; t >= 0; --t) {
         for (int l = L - 1; l >= 0; --l) {
-            const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
             const float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
             float* dg = g.dgates + (int64_t)l * T * G + t * G;
             CellBwd c{};
@@ -231,15 +293,35 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
             c.c_prev = cs_l + t * BH; c.c_new = cs_l + (t + 1) * BH;
             c.dh_rec = g.dh + l * BH;
             if (l < L - 1) {
-                c.dh_above = g.dxa + l * BH; c.above_stride_b = H;
                 c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
+                if (!fusedb) { c.dh_above = g.dxa + l * BH; c.above_stride_b = H; }
             } else {
                 c.dh_extra = g.dhtop + t * BH; c.extra_stride_b = H;
             }
             c.dc = g.dc + l * BH; c.dgates = dg; c.ld_dg = 4 * H;
             c.lens = d.lens; c.t = t;
+            if (fusedb) {
+                // dh_l(t) = dgates_l(t+1) W_hh_l  [+ dscores(t+1) W_attn_h for the top layer: the query of step
+                // t+1 used h_top(t)]  [+ mask_l(t) * dgates_{l+1}(t) W_ih_{l+1}: gradient of the input of the
+                // layer above]  + carried / extra terms; then the cell backward — one launch.
+                SkinnyPair prs[3];
+                int np = 0;
+                if (t < T - 1) {
+                    prs[np++] = SkinnyPair{g.dgates + (int64_t)l * T * G + (t + 1) * G, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+                    if (l == L - 1)
+                        prs[np++] = SkinnyPair{g.dscores + (int64_t)(t + 1) * B * ldD, ldD, d.w_attn_hT, ldS, ldS, 0};
+                }
+                if (l < L - 1)
+                    prs[np++] = SkinnyPair{g.dgates + (int64_t)(l + 1) * T * G + t * G, 4 * H, d.w_ihT[l + 1], 4 * H, 4 * H, 1};
+                if (np > 0) MMQG_TRY(skinny_cell_bwd(prs, np, c, s));
+                else MMQG_TRY(lstm_cell_bwd(c, s));
+                if (l == 0) {   // dctx(t) = dgates_0(t) * W_ih0[:, E:]
+                    const SkinnyPair pc{dg, 4 * H, d.w_ih0cT, 4 * H, 4 * H, 0};
+                    MMQG_TRY(skinny_plain(B, C, &pc, 1, nullptr, 0, g.dctx + (int64_t)t * B * C, C, s));
+                }
+                continue;
+            }
             MMQG_TRY(lstm_cell_bwd(c, s));
-            (void)hs_l;
             MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, 4 * H, dg, 4 * H, d.w_hh[l], H, nullptr, 0, nullptr, 0, 0,
                               nullptr, nullptr, 1, g.dh + l * BH, H, -1, s));
             if (l > 0) {
@@ -252,9 +334,20 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
         }
         float* ds = g.dscores + (int64_t)t * B * ldD;
         MMQG_TRY(attn_context_bwd(v, d.attn + (int64_t)t * B * ldS, ldS, g.dctx + (int64_t)t * B * C, C, nullptr, 0, ds, ldD, s));
-        // gradient of the query's h_top(t-1) half: feeds the top layer's recurrent gradient
-        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, S, ds, ldD, d.w_attn + E, Q, nullptr, 0, nullptr, 0, 0,
-                          nullptr, nullptr, 1, g.dh + (int64_t)(L - 1) * BH, H, -1, s));
+        if (!fusedb)   // gradient of the query's h_top(t-1) half: feeds the top layer's recurrent gradient
+            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, S, ds, ldD, d.w_attn + E, Q, nullptr, 0, nullptr, 0, 0,
+                              nullptr, nullptr, 1, g.dh + (int64_t)(L - 1) * BH, H, -1, s));
+    }
+    if (fusedb) {
+        // gradient of the initial state (the text encoder's final state): carry + dgates_l(0) W_hh_l
+        // (+ dscores(0) W_attn_h for the top layer, whose h0 was the query of step 0)
+        for (int l = 0; l < L; ++l) {
+            SkinnyPair prs[2];
+            int np = 0;
+            prs[np++] = SkinnyPair{g.dgates + (int64_t)l * T * G, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+            if (l == L - 1) prs[np++] = SkinnyPair{g.dscores, ldD, d.w_attn_hT, ldS, ldS, 0};
+            MMQG_TRY(skinny_plain(B, H, prs, np, nullptr, 1, g.dh + l * BH, H, s));
+        }
     }
     const int R = T * B;
     const float* htop_prev = d.hs + (int64_t)(L - 1) * (T + 1) * BH;   // rows t = h_top(t-1)

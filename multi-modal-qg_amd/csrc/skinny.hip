@@ -1,0 +1,384 @@
+// Batch-sized ("skinny", M = questions per GPU) products of the recurrent loops, fused with the
+// step's pointwise epilogue so ONE launch does a whole LSTM layer-step:
+//
+//   acc[b][n] = sum over up to 3 operand pairs of  A_p[b][:K_p] . B_p[n][:K_p]      (all k-major)
+//
+//   PLAIN     C = (beta ? C : 0) + bias + acc                      (scores += h_top W_attn_h^T, dctx, dh0)
+//   FWD_CELL  n runs over gate columns; acc (+ hoisted pre-activations + biases) -> LSTM cell
+//             update -> h, c, activated gates, dropped h, masked top output
+//             (model/encoder.py:54,91 and model/decoder.py:69 nn.LSTM, one time step)
+//   BWD_CELL  n runs over hidden units; acc = recurrent + from-above gradient of h(t) (the latter
+//             through that layer's dropout mask) -> cell backward -> dgates(t), dc
+//
+// Why not the tiled LDS GEMM: at M = 64 a layer-step is 0.13-0.43 GFLOP spread over only
+// 64x2048 (or 64x512) outputs; what bounds it is launch + memory latency, not MFMA throughput.
+// So: one workgroup per 16x16 output tile, its KS wavefronts split K between them (no atomics,
+// no zero-fill pass, no second kernel), operands go global -> VGPR directly as 16-byte lane
+// loads issued four k-chunks ahead (GEMV-style, no LDS round trip), v_mfma_f32_16x16x4_f32
+// (exact fp32) does the arithmetic, the KS partial tiles are combined through 2-4 KB of LDS and
+// the epilogue runs on the tile's 256 outputs.  512 (fwd) / 128-256 (bwd) workgroups of 4-8
+// waves fill the 256 CUs.  Backward products use transposed weight copies (refreshed after each
+// optimizer step by transpose_f32) so that every B operand is k-major too.
+#include <stdlib.h>
+
+#include "mmqg_common.h"
+#include "mmqg_kernels.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { MODE_PLAIN = 0, MODE_FWD_CELL = 1, MODE_BWD_CELL = 2 };
+
+struct Pair {
+    const float* A; int lda;
+    const float* B; int ldb;
+    int K;
+    int masked;     // BWD_CELL: multiply this pair's product by the dropout mask of (stream_id, b, j)
+};
+
+struct SkinnyK {
+    int M, N;
+    Pair p[3];
+    int cs1, cs2, chunks;          // first chunk of pair 1 / pair 2, total 16-wide k-chunks
+    // PLAIN
+    float* C; int ldc; int beta; const float* bias;
+    // cell (both directions)
+    int H;
+    const int32_t* lens; int t;
+    float drop_p; uint64_t seed; uint64_t stream_id; const int32_t* seed_off;
+    // FWD_CELL
+    float* gates; int gates_has_pre; const float* bias1; const float* bias2;
+    const float* h_prev; const float* c_prev; float* h_out; float* c_out; float* h_drop;
+    float* y_out; int64_t y_stride_b;
+    // BWD_CELL
+    const float* gates_act; const float* c_new;   // c_prev shared with fwd field
+    float* carry;                                  // [M][H] in: carried gradient of finished rows / dhT; out: carry for t-1
+    const float* above; int64_t above_stride_b;    // element-wise gradient from the layer above (masked)
+    const float* extra; int64_t extra_stride_b;    // further gradient of h(t), active rows only
+    float* dc; float* dgates;
+};
+
+__device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const int32_t* off) {
+    return off ? seed + (uint64_t)(uint32_t)off[0] * 0x9E3779B97F4A7C15ull : seed;
+}
+
+template <int MODE, int KS>
+__global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyK a) {
+    __shared__ float part[2][KS][16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, kq = lane >> 4;      // MFMA operand slot of this lane: tile row/col c, k-slot kq
+    const int m0 = blockIdx.y * 16;
+    const int n0 = blockIdx.x * (MODE == MODE_FWD_CELL ? 4 : 16);     // FWD: first hidden unit of the tile
+    // Global loads are issued with 4 adjacent lanes on 64 contiguous bytes of ONE row (lr = lane>>2,
+    // 16-byte segment ls = lane&3) so each lane quad is one cache-line access; a lane-per-row order
+    // (what the MFMA operand layout wants) made every wave load 64 separate line accesses and the
+    // kernel L1-bound.  One ds_bpermute per dword then moves the data to the MFMA slots:
+    // slot (c, kq) takes from loader lane 4*c + kq.
+    const int lr = lane >> 2, ls = lane & 3;
+    const int src_lane = 4 * c + kq;
+    const int ra = min(m0 + lr, a.M - 1);
+    int nb;
+    if (MODE == MODE_FWD_CELL) nb = (lr >> 2) * a.H + n0 + (lr & 3);  // gate block (lr>>2), unit n0 + (lr&3)
+    else nb = min(n0 + lr, a.N - 1);
+
+    const int per = (a.chunks + KS - 1) / KS;
+    const int q0 = wave * per, q1 = min(a.chunks, q0 + per);
+
+    // Epilogue operands are requested now so their latency hides behind the operand stream.
+    const int e_row = (threadIdx.x >> 4) & 15, e_col = threadIdx.x & 15;
+    const int e_b = m0 + e_row;
+    float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f, pf4 = 0.f, pf5 = 0.f;
+    if (threadIdx.x < 256 && e_b < a.M) {
+        if (MODE == MODE_FWD_CELL) {
+            const int gc = (e_col >> 2) * a.H + n0 + (e_col & 3);
+            if (a.gates_has_pre) pf0 = a.gates[(int64_t)e_b * 4 * a.H + gc];
+            if (a.bias1) pf0 += a.bias1[gc];
+            if (a.bias2) pf0 += a.bias2[gc];
+            if ((e_col >> 2) == 0) {
+                const int64_t e = (int64_t)e_b * a.H + n0 + (e_col & 3);
+                pf1 = a.h_prev[e];
+                pf2 = a.c_prev[e];
+            }
+        } else if (MODE == MODE_BWD_CELL) {
+            const int j = n0 + e_col;
+            if (j < a.H) {
+                const int64_t e = (int64_t)e_b * a.H + j;
+                pf0 = a.carry[e];
+                pf1 = a.c_new[e];
+                pf2 = a.dc[e];
+                pf3 = a.c_prev[e];
+                if (a.above) pf4 = a.above[(int64_t)e_b * a.above_stride_b + j];
+                if (a.extra) pf5 = a.extra[(int64_t)e_b * a.extra_stride_b + j];
+            }
+        }
+    }
+
+    f32x4 acc_p = {0.f, 0.f, 0.f, 0.f}, acc_m = {0.f, 0.f, 0.f, 0.f};
+    // The pair loop is unrolled with compile-time pair indices: indexing the kernel-argument array with
+    // a run-time value made hipcc fetch the Pair fields with per-lane global loads and a vmcnt(0) wait
+    // in front of every operand load (a dependent-load chain per k-chunk).
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
+        const int pbeg = pi == 0 ? 0 : (pi == 1 ? a.cs1 : a.cs2);
+        const int pend = pi == 0 ? min(a.cs1, a.chunks) : (pi == 1 ? min(a.cs2, a.chunks) : a.chunks);
+        const int lo = max(q0, pbeg), hi = min(q1, pend);
+        if (lo >= hi) continue;
+        const float* __restrict__ Ap = a.p[pi].A + (int64_t)ra * a.p[pi].lda;
+        const float* __restrict__ Bp = a.p[pi].B + (int64_t)nb * a.p[pi].ldb;
+        const int K = a.p[pi].K;
+        const bool masked = (MODE == MODE_BWD_CELL) && a.p[pi].masked;
+        constexpr int U = 8;     // k-chunks in flight per wave: 16 x 16-byte loads, one latency exposure
+        for (int q = lo; q < hi; q += U) {
+            float4 av[U], bv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = (q + u - pbeg) * 16 + 4 * ls;
+                av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[u] = av[u];
+                if (q + u < hi && k < K) {
+                    av[u] = *reinterpret_cast<const float4*>(Ap + k);
+                    bv[u] = *reinterpret_cast<const float4*>(Bp + k);
+                }
+            }
+            // all lane permutes of the group first, then the MFMAs: left to itself hipcc pairs every
+            // MFMA with its two ds_bpermute and an lgkmcnt(0) wait, i.e. one LDS round trip per MFMA
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                av[u].x = __shfl(av[u].x, src_lane, 64); bv[u].x = __shfl(bv[u].x, src_lane, 64);
+                av[u].y = __shfl(av[u].y, src_lane, 64); bv[u].y = __shfl(bv[u].y, src_lane, 64);
+                av[u].z = __shfl(av[u].z, src_lane, 64); bv[u].z = __shfl(bv[u].z, src_lane, 64);
+                av[u].w = __shfl(av[u].w, src_lane, 64); bv[u].w = __shfl(bv[u].w, src_lane, 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (masked) {
+                    acc_m = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u].x, acc_m, 0, 0, 0);
+                    acc_m = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u].y, acc_m, 0, 0, 0);
+                    acc_m = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u].z, acc_m, 0, 0, 0);
+                    acc_m = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u].w, acc_m, 0, 0, 0);
+                } else {
+                    acc_p = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u].x, acc_p, 0, 0, 0);
+                    acc_p = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u].y, acc_p, 0, 0, 0);
+                    acc_p = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u].z, acc_p, 0, 0, 0);
+                    acc_p = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u].w, acc_p, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[0][wave][kq * 4 + r][c] = acc_p[r];
+        if (MODE == MODE_BWD_CELL) part[1][wave][kq * 4 + r][c] = acc_m[r];
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid >= 256) { if (MODE != MODE_FWD_CELL) return; }
+    const int row = (tid >> 4) & 15, col = tid & 15;
+    float s = 0.f, sm = 0.f;
+    if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < KS; ++w) {
+            s += part[0][w][row][col];
+            if (MODE == MODE_BWD_CELL) sm += part[1][w][row][col];
+        }
+    }
+    const int b = m0 + row;
+
+    if (MODE == MODE_PLAIN) {
+        const int n = n0 + col;
+        if (b < a.M && n < a.N) {
+            float* dst = a.C + (int64_t)b * a.ldc + n;
+            float v = s + (a.bias ? a.bias[n] : 0.f);
+            if (a.beta) v += *dst;
+            *dst = v;
+        }
+        return;
+    }
+
+    if (MODE == MODE_FWD_CELL) {
+        const int H = a.H;
+        const int g = col >> 2, j = n0 + (col & 3);
+        const float pre = s + pf0;
+        __syncthreads();                        // all partial sums consumed: reuse part[0][0] for the tile
+        if (tid < 256) part[0][0][row][col] = pre;
+        __syncthreads();
+        if (tid >= 256 || b >= a.M) return;
+        const bool active = a.lens ? (a.t < a.lens[b]) : true;
+        float* grow = a.gates + (int64_t)b * 4 * H;
+        // each of the 4 gate lanes of (b, j) stores its own activated gate; lane g == 0 also does the state
+        const float gi = sigmoidf_(part[0][0][row][0 + (col & 3)]);
+        const float gf = sigmoidf_(part[0][0][row][4 + (col & 3)]);
+        const float gg = tanhf(part[0][0][row][8 + (col & 3)]);
+        const float go = sigmoidf_(part[0][0][row][12 + (col & 3)]);
+        const float mine = g == 0 ? gi : (g == 1 ? gf : (g == 2 ? gg : go));
+        grow[g * H + j] = active ? mine : 0.f;
+        if (g != 0) return;
+        const int64_t e = (int64_t)b * H + j;
+        const float hp = pf1, cp = pf2;
+        float h = hp, cc = cp;
+        if (active) {
+            cc = gf * cp + gi * gg;
+            h = go * tanhf(cc);
+        }
+        a.h_out[e] = h;
+        a.c_out[e] = cc;
+        if (a.h_drop) a.h_drop[e] = active ? h * dropout_scale(eff_seed(a.seed, a.seed_off), a.stream_id, (uint64_t)e, a.drop_p) : 0.f;
+        if (a.y_out) a.y_out[(int64_t)b * a.y_stride_b + j] = active ? h : 0.f;
+        return;
+    }
+
+    // MODE_BWD_CELL
+    {
+        const int H = a.H;
+        const int j = n0 + col;
+        if (b >= a.M || j >= H) return;
+        const int64_t e = (int64_t)b * H + j;
+        float mask = 1.f;
+        bool have_mask = false;
+        float dh = s + pf0;
+        if (a.p[1].masked || a.p[2].masked || a.p[0].masked) {
+            if (a.drop_p > 0.f) { mask = dropout_scale(eff_seed(a.seed, a.seed_off), a.stream_id, (uint64_t)e, a.drop_p); }
+            have_mask = true;
+            dh += sm * mask;
+        }
+        const bool active = a.lens ? (a.t < a.lens[b]) : true;
+        float* dg = a.dgates + (int64_t)b * 4 * H;
+        if (!active) {
+            dg[j] = 0.f; dg[H + j] = 0.f; dg[2 * H + j] = 0.f; dg[3 * H + j] = 0.f;
+            a.carry[e] = dh;                    // state was carried forward, so is its gradient
+            return;
+        }
+        if (a.above) {
+            if (!have_mask && a.drop_p > 0.f) mask = dropout_scale(eff_seed(a.seed, a.seed_off), a.stream_id, (uint64_t)e, a.drop_p);
+            dh += pf4 * mask;
+        }
+        if (a.extra) dh += pf5;
+        const float* gr = a.gates_act + (int64_t)b * 4 * H;
+        const float gi = gr[j], gf = gr[H + j], gg = gr[2 * H + j], go = gr[3 * H + j];
+        const float tc = tanhf(pf1);
+        const float dct = pf2 + dh * go * (1.f - tc * tc);
+        dg[j] = dct * gg * gi * (1.f - gi);
+        dg[H + j] = dct * pf3 * gf * (1.f - gf);
+        dg[2 * H + j] = dct * gi * (1.f - gg * gg);
+        dg[3 * H + j] = dh * tc * go * (1.f - go);
+        a.dc[e] = dct * gf;
+        a.carry[e] = 0.f;
+    }
+}
+
+// dst[c][r] = src[r][c]   (rows x cols -> cols x rows), 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int ld_src, int rows, int cols,
+                                                        float* __restrict__ dst, int ld_dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, cc = c0 + tx;
+        tile[ty + i][tx] = (r < rows && cc < cols) ? src[(int64_t)r * ld_src + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int cc = c0 + ty + i, r = r0 + tx;
+        if (cc < cols && r < rows) dst[(int64_t)cc * ld_dst + r] = tile[tx][ty + i];
+    }
+}
+
+bool pair_ok(const mmqg::SkinnyPair& p) {
+    return p.A && p.B && p.K > 0 && p.K % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 && mmqg::aligned16(p.A) &&
+           mmqg::aligned16(p.B);
+}
+
+template <int MODE>
+int launch_skinny(const SkinnyK& k, int tiles_n, hipStream_t s, const char* what) {
+    dim3 grid(tiles_n, mmqg::ceil_div(k.M, 16));
+    // enough K per wave to amortise the reduction; 8 waves once a tile has >= 64 chunks
+    static const int ks8_from = [] { const char* e = getenv("MMQG_SKINNY_KS8_FROM"); return e ? atoi(e) : 64; }();
+    if (k.chunks >= ks8_from) hipLaunchKernelGGL((skinny_kernel<MODE, 8>), grid, dim3(512), 0, s, k);
+    else hipLaunchKernelGGL((skinny_kernel<MODE, 4>), grid, dim3(256), 0, s, k);
+    return mmqg::check_launch(what);
+}
+
+int fill_pairs(SkinnyK& k, const mmqg::SkinnyPair* pairs, int npairs, const char* who) {
+    MMQG_REQUIRE(npairs >= 1 && npairs <= 3, "%s: need 1..3 operand pairs", who);
+    int chunks = 0;
+    k.cs1 = k.cs2 = 1 << 30;
+    for (int i = 0; i < 3; ++i) {
+        if (i < npairs) {
+            MMQG_REQUIRE(pair_ok(pairs[i]), "%s: operand pair %d is not 16-byte aligned / K,ld not multiples of 4", who, i);
+            k.p[i] = Pair{pairs[i].A, pairs[i].lda, pairs[i].B, pairs[i].ldb, pairs[i].K, pairs[i].masked};
+            if (i == 1) k.cs1 = chunks;
+            if (i == 2) k.cs2 = chunks;
+            chunks += mmqg::ceil_div(pairs[i].K, 16);
+        } else {
+            k.p[i] = Pair{nullptr, 0, nullptr, 0, 0, 0};
+        }
+    }
+    k.chunks = chunks;
+    return 0;
+}
+
+}  // namespace
+
+namespace mmqg {
+
+bool skinny_usable(const SkinnyPair* pairs, int npairs) {
+    for (int i = 0; i < npairs; ++i)
+        if (!pair_ok(pairs[i])) return false;
+    return npairs >= 1 && npairs <= 3;
+}
+
+int skinny_plain(int M, int N, const SkinnyPair* pairs, int npairs, const float* bias, int beta, float* C, int ldc,
+                 hipStream_t s) {
+    MMQG_REQUIRE(M >= 0 && N >= 0 && C && ldc >= N, "skinny_plain: bad arguments");
+    if (M == 0 || N == 0) return 0;
+    SkinnyK k{};
+    MMQG_TRY(fill_pairs(k, pairs, npairs, "skinny_plain"));
+    k.M = M; k.N = N; k.C = C; k.ldc = ldc; k.beta = beta ? 1 : 0; k.bias = bias;
+    return launch_skinny<MODE_PLAIN>(k, ceil_div(N, 16), s, "skinny_plain");
+}
+
+int skinny_cell_fwd(const SkinnyPair* pairs, int npairs, int gates_has_pre, const float* bias1, const float* bias2,
+                    const CellFwd& f, hipStream_t s) {
+    MMQG_REQUIRE(f.B >= 0 && f.H > 0 && f.H % 4 == 0 && f.ld_g == 4 * f.H, "skinny_cell_fwd: need H %% 4 == 0 and compact gates");
+    if (f.B == 0) return 0;
+    MMQG_REQUIRE(f.gates && f.h_prev && f.c_prev && f.h_out && f.c_out, "skinny_cell_fwd: null pointer");
+    SkinnyK k{};
+    MMQG_TRY(fill_pairs(k, pairs, npairs, "skinny_cell_fwd"));
+    k.M = f.B; k.N = 4 * f.H; k.H = f.H;
+    k.lens = f.lens; k.t = f.t; k.drop_p = f.p; k.seed = f.seed; k.stream_id = f.stream_id; k.seed_off = f.seed_off;
+    k.gates = f.gates; k.gates_has_pre = gates_has_pre; k.bias1 = bias1; k.bias2 = bias2;
+    k.h_prev = f.h_prev; k.c_prev = f.c_prev; k.h_out = f.h_out; k.c_out = f.c_out; k.h_drop = f.h_drop;
+    k.y_out = f.y_out; k.y_stride_b = f.y_stride_b;
+    return launch_skinny<MODE_FWD_CELL>(k, f.H / 4, s, "skinny_cell_fwd");
+}
+
+int skinny_cell_bwd(const SkinnyPair* pairs, int npairs, const CellBwd& f, hipStream_t s) {
+    MMQG_REQUIRE(f.B >= 0 && f.H > 0 && f.ld_dg == 4 * f.H, "skinny_cell_bwd: need compact dgates");
+    if (f.B == 0) return 0;
+    MMQG_REQUIRE(f.gates_act && f.c_prev && f.c_new && f.dh_rec && f.dc && f.dgates, "skinny_cell_bwd: null pointer");
+    SkinnyK k{};
+    MMQG_TRY(fill_pairs(k, pairs, npairs, "skinny_cell_bwd"));
+    k.M = f.B; k.N = f.H; k.H = f.H;
+    k.lens = f.lens; k.t = f.t; k.drop_p = f.p; k.seed = f.seed; k.stream_id = f.stream_id; k.seed_off = f.seed_off;
+    k.gates_act = f.gates_act; k.c_prev = f.c_prev; k.c_new = f.c_new; k.carry = f.dh_rec;
+    k.above = f.dh_above; k.above_stride_b = f.above_stride_b; k.extra = f.dh_extra; k.extra_stride_b = f.extra_stride_b;
+    k.dc = f.dc; k.dgates = f.dgates;
+    return launch_skinny<MODE_BWD_CELL>(k, ceil_div(f.H, 16), s, "skinny_cell_bwd");
+}
+
+int transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s) {
+    MMQG_REQUIRE(rows >= 0 && cols >= 0 && src && dst && ld_src >= cols && ld_dst >= rows, "transpose_f32: bad arguments");
+    if (rows == 0 || cols == 0) return 0;
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0, s, src, ld_src, rows,
+                       cols, dst, ld_dst);
+    return check_launch("transpose_f32");
+}
+
+}  // namespace mmqg

@@ -178,6 +178,10 @@ class BatchedTrainer:
         w["dgates_t"], w["dxl_t"], w["dh_t"], w["dc_t"] = f(L, Tc, B, 4 * H), f(Tc, B, H), f(B, H), f(B, H)
         w["dxemb_c"] = f(Tc, B, E)
         w["dgates_v"], w["dh_v"], w["dc_v"], w["dfeats"] = f(1, Tf, B, 4 * Hv), f(B, Hv), f(B, Hv), f(Tf, B, Fin)
+        # k-major (transposed) copies of the recurrent weights for the fused backward time loops
+        w["whhT_v"] = f(1, Hv, 4 * Hv)
+        w["whhT_t"], w["whhT_d"], w["wihT_d"] = f(L, H, 4 * H), f(L, H, 4 * H), f(L, H, 4 * H)
+        w["wih0cT"], w["wattn_hT"] = f(Cw, 4 * H), f(H, ldS)
 
     # ----------------------------------------------------------------------- descriptors
     def _lstm_ptrs(self, d, params, grads=None):
@@ -204,6 +208,7 @@ class BatchedTrainer:
         gv.dy, gv.dy_stride_t, gv.dy_stride_b = w["dvideo"].data_ptr(), B * self.Hv, self.Hv
         gv.dgates, gv.dh, gv.dc = w["dgates_v"].data_ptr(), w["dh_v"].data_ptr(), w["dc_v"].data_ptr()
         gv.dx, gv.lddx = w["dfeats"].data_ptr(), self.Fin
+        dv.w_hhT[0] = w["whhT_v"].data_ptr()
         self.d_vid, self.g_vid = dv, gv
         # text encoder -> text rows of the value tensor
         dt, gt = _lib.LstmSeq(), _lib.LstmSeqGrad()
@@ -219,6 +224,8 @@ class BatchedTrainer:
         gt.dhT, gt.dcT = w["dh_d"].data_ptr(), w["dc_d"].data_ptr()      # gradient of the state handed to the decoder
         gt.dgates, gt.dxl, gt.dh, gt.dc = (w[k].data_ptr() for k in ("dgates_t", "dxl_t", "dh_t", "dc_t"))
         gt.dx, gt.lddx = w["dxemb_c"].data_ptr(), self.E
+        for l in range(L):
+            dt.w_hhT[l] = w["whhT_t"][l].data_ptr()
         self.d_text, self.g_text = dt, gt
         # decoder
         dd, gd = _lib.DecoderSeq(), _lib.DecoderSeqGrad()
@@ -248,6 +255,11 @@ class BatchedTrainer:
         gd.dtext_stride_row, gd.dtext_stride_b = B * H, H
         gd.n_video_rows, gd.dvideo = self.Tf, w["dvideo"].data_ptr()
         gd.dvideo_stride_row, gd.dvideo_stride_b = B * self.Hv, self.Hv
+        for l in range(L):
+            dd.w_hhT[l] = w["whhT_d"][l].data_ptr()
+            if l > 0:
+                dd.w_ihT[l] = w["wihT_d"][l].data_ptr()
+        dd.w_ih0cT, dd.w_attn_hT = w["wih0cT"].data_ptr(), w["wattn_hT"].data_ptr()
         self.d_dec, self.g_dec = dd, gd
 
     # ------------------------------------------------------------------------------ modes
@@ -325,7 +337,27 @@ class BatchedTrainer:
             if self.grad_hook:
                 self.grad_hook(self, "rest")
 
+    def _refresh_transposes(self):
+        """k-major copies of the recurrent weights for the backward loops.  Done at the start of
+        every backward (9 small launches, ~45 MB moved) so externally loaded weights are honoured."""
+        lib, s, w = _lib.load(), ops._stream(), self.ws
+        H, L, Hv = self.H, self.L, self.Hv
+
+        def tr(src_ptr, ld_src, rows, cols, dst, ld_dst):
+            check(lib.mmqg_transpose_f32(src_ptr, ld_src, rows, cols, dst.data_ptr(), ld_dst, s), "transpose_f32")
+
+        tr(self.video.lstm.weight_hh_l0.data_ptr(), Hv, 4 * Hv, Hv, w["whhT_v"][0], 4 * Hv)
+        for l in range(L):
+            tr(getattr(self.text.lstm, f"weight_hh_l{l}").data_ptr(), H, 4 * H, H, w["whhT_t"][l], 4 * H)
+            tr(getattr(self.dec.lstm, f"weight_hh_l{l}").data_ptr(), H, 4 * H, H, w["whhT_d"][l], 4 * H)
+            if l > 0:
+                tr(getattr(self.dec.lstm, f"weight_ih_l{l}").data_ptr(), H, 4 * H, H, w["wihT_d"][l], 4 * H)
+        In0 = self.E + self.Cw
+        tr(self.dec.lstm.weight_ih_l0.data_ptr() + 4 * self.E, In0, 4 * H, self.Cw, w["wih0cT"], 4 * H)
+        tr(self.dec.text_attn.weight.data_ptr() + 4 * self.E, self.E + H, self.S, H, w["wattn_hT"], self.ldS)
+
     def _backward_decoder(self):
+        self._refresh_transposes()
         lib, s, w = _lib.load(), ops._stream(), self.ws
         L, B, H, V, E = self.L, self.B, self.H, self.V, self.E
         R = self.Td * B

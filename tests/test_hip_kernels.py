@@ -412,3 +412,14 @@ def test_lstm_sequence_executor_forward_backward(mm, T, B, L, H, In, p):
         for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
             close(flat[i].grad, pd[f"lstm.{n}_l{l}"].grad.float(), what=f"d{n}_l{l}")
             i += 1
+
+
+def test_transpose(mm):
+    _lib, ops = mm
+    g = torch.Generator().manual_seed(8)
+    src = torch.randn(77, 130 + 6, generator=g)
+    s_d = dev(src)
+    dst = torch.full((130, 80), -1.0, device="cuda")
+    _lib.check(_lib.load().mmqg_transpose_f32(s_d.data_ptr(), 136, 77, 130, dst.data_ptr(), 80, ops._stream()))
+    assert torch.equal(dst[:, :77].cpu(), src[:, :130].t())
+    assert torch.all(dst[:, 77:] == -1.0)
