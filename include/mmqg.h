@@ -173,6 +173,11 @@ typedef struct {
     float* dw_ih[MMQG_MAX_LAYERS]; float* dw_hh[MMQG_MAX_LAYERS];
     float* db_ih[MMQG_MAX_LAYERS]; float* db_hh[MMQG_MAX_LAYERS];
     float* dh0; float* dc0;                         /* [L][B][H] out, nullable */
+    int32_t phase;                                  /* 0 = everything; 1 = the time loops only (+ the
+                                                       inter-layer input gradients they need); 2 = weight and
+                                                       bias gradients + dx only (after a phase-1 call).  Lets a
+                                                       caller run the large, recurrence-free GEMMs of phase 2 on
+                                                       a second stream beside another sequence's time loop. */
 } mmqg_lstm_seq_grad;
 
 int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream);
@@ -205,6 +210,8 @@ typedef struct {
     float* gates;                                   /* [L][T][B][4H] */
     float* hs; float* cs;                           /* [L][T+1][B][H] */
     float* hdrop;                                   /* [L-1][T][B][H] or NULL */
+    int32_t phase;                                  /* 0 = everything; 1 = hoisted products only (need only
+                                                       xemb); 2 = state init + time loop (after phase 1) */
 } mmqg_decoder_seq;
 
 typedef struct {
@@ -221,6 +228,9 @@ typedef struct {
     /* gradient of the leading value rows (the only ones an encoder produced) */
     int32_t n_text_rows;  float* dtext;  int64_t dtext_stride_row;  int64_t dtext_stride_b;
     int32_t n_video_rows; float* dvideo; int64_t dvideo_stride_row; int64_t dvideo_stride_b;
+    int32_t phase;                                  /* 0 = everything; 1 = time loop + initial-state and value
+                                                       gradients (what the encoders' backward needs); 2 = dxemb,
+                                                       weight and bias gradients */
 } mmqg_decoder_seq_grad;
 
 int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream);

@@ -53,7 +53,7 @@ class LstmSeqGrad(C.Structure):
                 ("dgates", c_f), ("dxl", c_f), ("dh", c_f), ("dc", c_f),
                 ("dx", c_f), ("lddx", C.c_int32),
                 ("dw_ih", _PTRS), ("dw_hh", _PTRS), ("db_ih", _PTRS), ("db_hh", _PTRS),
-                ("dh0", c_f), ("dc0", c_f)]
+                ("dh0", c_f), ("dc0", c_f), ("phase", C.c_int32)]
 
 
 class DecoderSeq(C.Structure):
@@ -66,7 +66,7 @@ class DecoderSeq(C.Structure):
                 ("dropout_p", c_fl), ("training", C.c_int32), ("seed", c_u64), ("stream_base", c_u64),
                 ("seed_offset", c_f),
                 ("scores", c_f), ("attn", c_f), ("ld_attn", C.c_int32),
-                ("ctx", c_f), ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f)]
+                ("ctx", c_f), ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f), ("phase", C.c_int32)]
 
 
 class DecoderSeqGrad(C.Structure):
@@ -75,7 +75,8 @@ class DecoderSeqGrad(C.Structure):
                 ("dw_attn", c_f), ("db_attn", c_f),
                 ("dw_ih", _PTRS), ("dw_hh", _PTRS), ("db_ih", _PTRS), ("db_hh", _PTRS),
                 ("n_text_rows", C.c_int32), ("dtext", c_f), ("dtext_stride_row", c_i64), ("dtext_stride_b", c_i64),
-                ("n_video_rows", C.c_int32), ("dvideo", c_f), ("dvideo_stride_row", c_i64), ("dvideo_stride_b", c_i64)]
+                ("n_video_rows", C.c_int32), ("dvideo", c_f), ("dvideo_stride_row", c_i64), ("dvideo_stride_b", c_i64),
+                ("phase", C.c_int32)]
 
 
 # name -> argtypes (return type is int unless noted); kept in one table so the CPU test can

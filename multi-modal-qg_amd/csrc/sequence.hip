@@ -103,8 +103,9 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
     const int T = d.T, B = d.B, H = d.H, L = d.L;
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
     const bool drop = lstm_drop(d);
-    for (int l = L - 1; l >= 0; --l) {
-        const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
+    MMQG_REQUIRE(g.phase >= 0 && g.phase <= 2, "lstm_seq_bwd: phase must be 0, 1 or 2");
+    const bool do_loop = g.phase != 2, do_wgrad = g.phase != 1;
+    for (int l = L - 1; l >= 0 && do_loop; --l) {
         const float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
         const float* gates_l = d.gates + (int64_t)l * T * G;
         float* dg_l = g.dgates + (int64_t)l * T * G;
@@ -142,26 +143,31 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
         }
         if (g.dh0) MMQG_TRY(copy_or_zero(g.dh0 + l * BH, g.dh, (size_t)BH, s));
         if (g.dc0) MMQG_TRY(copy_or_zero(g.dc0 + l * BH, g.dc, (size_t)BH, s));
+        // gradient wrt the layer input, all steps at once: the next (lower) layer's loop consumes it
+        if (l > 0)
+            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, T * B, H, 4 * H, dg_l, 4 * H, d.w_ih[l], H, nullptr, 0, nullptr,
+                              0, 0, nullptr, nullptr, 0, g.dxl, H, -1, s));
+    }
+    for (int l = L - 1; l >= 0 && do_wgrad; --l) {
+        const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
+        const float* dg_l = g.dgates + (int64_t)l * T * G;
         const float* X; int ldx, in;
         if (l == 0) { X = d.x; ldx = d.ldx; in = d.In; }
         else { X = drop ? d.hdrop + (int64_t)(l - 1) * T * BH : d.hs + (int64_t)(l - 1) * (T + 1) * BH + BH; ldx = H; in = H; }
-        // gradient wrt the layer input, all steps at once
-        if (l > 0) {
-            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, T * B, H, 4 * H, dg_l, 4 * H, d.w_ih[l], H, nullptr, 0, nullptr,
-                              0, 0, nullptr, nullptr, 0, g.dxl, H, -1, s));
-        } else if (g.dx) {
-            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, T * B, in, 4 * H, dg_l, 4 * H, d.w_ih[0], in, nullptr, 0,
-                              nullptr, 0, 0, nullptr, nullptr, 0, g.dx, g.lddx, -1, s));
+        {
+            // recurrence-free products over all T*B rows: layer-0 input gradient, weight / bias gradients
+            if (l == 0 && g.dx)
+                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, T * B, in, 4 * H, dg_l, 4 * H, d.w_ih[0], in, nullptr, 0,
+                                  nullptr, 0, 0, nullptr, nullptr, 0, g.dx, g.lddx, -1, s));
+            if (g.dw_ih[l])
+                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, in, T * B, dg_l, 4 * H, X, ldx, nullptr, 0, nullptr, 0,
+                                  0, nullptr, nullptr, 1, g.dw_ih[l], in, -1, s));
+            if (g.dw_hh[l])
+                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, H, T * B, dg_l, 4 * H, hs_l, H, nullptr, 0, nullptr, 0,
+                                  0, nullptr, nullptr, 1, g.dw_hh[l], H, -1, s));
+            if (g.db_ih[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_ih[l], s));
+            if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_hh[l], s));
         }
-        // weight gradients: dW += dGates^T * X over all T*B rows
-        if (g.dw_ih[l])
-            MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, in, T * B, dg_l, 4 * H, X, ldx, nullptr, 0, nullptr, 0,
-                              0, nullptr, nullptr, 1, g.dw_ih[l], in, -1, s));
-        if (g.dw_hh[l])
-            MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, H, T * B, dg_l, 4 * H, hs_l, H, nullptr, 0, nullptr, 0,
-                              0, nullptr, nullptr, 1, g.dw_hh[l], H, -1, s));
-        if (g.db_ih[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_ih[l], s));
-        if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_hh[l], s));
     }
     return 0;
 }
@@ -191,16 +197,22 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
     const int ldS = d.ld_attn;
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
     const bool drop = d.training && d.dropout_p > 0.f && L > 1;
-    for (int l = 0; l < L; ++l) {
-        MMQG_TRY(copy_or_zero(d.hs + (int64_t)l * (T + 1) * BH, d.h0 + l * BH, (size_t)BH, s));
-        MMQG_TRY(copy_or_zero(d.cs + (int64_t)l * (T + 1) * BH, d.c0 + l * BH, (size_t)BH, s));
+    MMQG_REQUIRE(d.phase >= 0 && d.phase <= 2, "decoder_seq_fwd: phase must be 0, 1 or 2");
+    if (d.phase != 1) {
+        for (int l = 0; l < L; ++l) {
+            MMQG_TRY(copy_or_zero(d.hs + (int64_t)l * (T + 1) * BH, d.h0 + l * BH, (size_t)BH, s));
+            MMQG_TRY(copy_or_zero(d.cs + (int64_t)l * (T + 1) * BH, d.c0 + l * BH, (size_t)BH, s));
+        }
     }
     if (T == 0) return 0;
-    // hoisted: embedded-word part of the scores (+ bias) and of the layer-0 gates (+ b_ih)
-    MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, S, E, d.xemb, E, d.w_attn, Q, nullptr, 0, nullptr, 0, 0,
-                      d.b_attn, nullptr, 0, d.scores, ldS, -1, s));
-    MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, 4 * H, E, d.xemb, E, d.w_ih[0], In0, nullptr, 0, nullptr, 0, 0,
-                      d.b_ih[0], d.b_hh[0], 0, d.gates, 4 * H, -1, s));
+    if (d.phase != 2) {
+        // hoisted: embedded-word part of the scores (+ bias) and of the layer-0 gates (+ b_ih + b_hh)
+        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, S, E, d.xemb, E, d.w_attn, Q, nullptr, 0, nullptr, 0, 0,
+                          d.b_attn, nullptr, 0, d.scores, ldS, -1, s));
+        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, 4 * H, E, d.xemb, E, d.w_ih[0], In0, nullptr, 0, nullptr, 0, 0,
+                          d.b_ih[0], d.b_hh[0], 0, d.gates, 4 * H, -1, s));
+    }
+    if (d.phase == 1) return 0;
     const float* htop_base = d.hs + (int64_t)(L - 1) * (T + 1) * BH;
     for (int t = 0; t < T; ++t) {
         float* sc = d.scores + (int64_t)t * B * ldS;
@@ -267,6 +279,9 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
     MMQG_REQUIRE(ldD >= S, "decoder_seq_bwd: ld_ds too small");
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
     const bool drop = d.training && d.dropout_p > 0.f && L > 1;
+    MMQG_REQUIRE(g.phase >= 0 && g.phase <= 2, "decoder_seq_bwd: phase must be 0, 1 or 2");
+    const bool do_loop = g.phase != 2, do_wgrad = g.phase != 1;
+    if (do_loop) {
     MMQG_TRY(copy_or_zero(g.dh, nullptr, (size_t)L * BH, s));
     MMQG_TRY(copy_or_zero(g.dc, nullptr, (size_t)L * BH, s));
     // fused backward: possible when k-major (transposed) copies of every recurrent weight are given
@@ -349,6 +364,16 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
             MMQG_TRY(skinny_plain(B, H, prs, np, nullptr, 1, g.dh + l * BH, H, s));
         }
     }
+    // gradient of the value rows an encoder produced (text rows feed the text encoder's
+    // backward, video rows the frame encoder's); audio features are inputs and get none
+    if (g.dtext && g.n_text_rows > 0)
+        MMQG_TRY(attn_dvalues(T, B, std::min(g.n_text_rows, v.Lt), v.H, d.attn, (int64_t)B * ldS, ldS, 0, g.dctx,
+                              (int64_t)B * C, C, 0, g.dtext, g.dtext_stride_row, g.dtext_stride_b, 0, s));
+    if (g.dvideo && g.n_video_rows > 0)
+        MMQG_TRY(attn_dvalues(T, B, std::min(g.n_video_rows, v.Lav), v.Dv, d.attn, (int64_t)B * ldS, ldS, v.Lt + v.Lav,
+                              g.dctx, (int64_t)B * C, C, v.H + v.Da, g.dvideo, g.dvideo_stride_row, g.dvideo_stride_b, 0, s));
+    }   // do_loop
+    if (!do_wgrad) return 0;
     const int R = T * B;
     const float* htop_prev = d.hs + (int64_t)(L - 1) * (T + 1) * BH;   // rows t = h_top(t-1)
     // embedded-word gradient: layer-0 gate path + score path
@@ -386,14 +411,6 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
         if (g.db_ih[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, R, 4 * H, g.db_ih[l], s));
         if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, R, 4 * H, g.db_hh[l], s));
     }
-    // gradient of the value rows an encoder produced (text rows feed the text encoder's
-    // backward, video rows the frame encoder's); audio features are inputs and get none
-    if (g.dtext && g.n_text_rows > 0)
-        MMQG_TRY(attn_dvalues(T, B, std::min(g.n_text_rows, v.Lt), v.H, d.attn, (int64_t)B * ldS, ldS, 0, g.dctx,
-                              (int64_t)B * C, C, 0, g.dtext, g.dtext_stride_row, g.dtext_stride_b, 0, s));
-    if (g.dvideo && g.n_video_rows > 0)
-        MMQG_TRY(attn_dvalues(T, B, std::min(g.n_video_rows, v.Lav), v.Dv, d.attn, (int64_t)B * ldS, ldS, v.Lt + v.Lav,
-                              g.dctx, (int64_t)B * C, C, v.H + v.Da, g.dvideo, g.dvideo_stride_row, g.dvideo_stride_b, 0, s));
     return 0;
 }
 

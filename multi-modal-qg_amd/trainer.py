@@ -82,6 +82,7 @@ class BatchedTrainer:
         self._describe()
         self.use_graph = use_graph
         self._graph = None
+        self._side = torch.cuda.Stream(device=self.dev)
         self.reducer = GradReducer(self.flat_g, trainer_buckets(self.segments, self.n_params), self.pg)
         if self.world > 1:
             broadcast_parameters(self.flat_p, self.pg)
@@ -305,41 +306,89 @@ class BatchedTrainer:
         return raw
 
     # ------------------------------------------------------------------------ one step
+    # Two HIP streams: the recurrent time loops are latency-bound chains of small launches, the
+    # hoisted products / weight gradients are large GEMMs with no recurrence — so they run beside
+    # each other (fork/join with events, which a hipGraph capture records as parallel branches):
+    #   forward : [frame LSTM, decoder hoists, weight transposes] || [text encoder]
+    #   backward: [vocab wgrad] || [vocab dgrad -> decoder loop], then
+    #             [decoder weight grads, frame LSTM backward] || [text encoder backward]
+    def _fork(self):
+        self._side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._side)
+
+    def _join(self):
+        torch.cuda.current_stream().wait_stream(self._side)
+
     def _forward(self, training: bool):
-        lib, s, w = _lib.load(), ops._stream(), self.ws
+        lib, w = _lib.load(), self.ws
         L, B, H, V = self.L, self.B, self.H, self.V
         for d in (self.d_vid, self.d_text, self.d_dec):
             d.training = int(training)
         self.d_text.dropout_p = self.drop_text if training else 0.0
         self.d_dec.dropout_p = self.drop_dec if training else 0.0
-        check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_vid), s), "lstm_seq_fwd(frames)")
         emb = self.dec.emb_layer.weight
+        with self._fork():
+            s = ops._stream()
+            check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_vid), s), "lstm_seq_fwd(frames)")
+            ops.embedding_fwd(emb, w["ids_d"], w["xemb_d"].view(-1, self.E))
+            self.d_dec.phase = 1
+            check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd(hoists)")
+            if training:
+                self._refresh_transposes()
+        s = ops._stream()
         ops.embedding_fwd(emb, w["ids_c"], w["xemb_c"].view(-1, self.E))
         check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_text), s), "lstm_seq_fwd(text)")
         w["h0_d"].copy_(w["hs_t"][:, self.Tc])
         w["c0_d"].copy_(w["cs_t"][:, self.Tc])
-        ops.embedding_fwd(emb, w["ids_d"], w["xemb_d"].view(-1, self.E))
-        check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd")
+        self._join()
+        self.d_dec.phase = 2
+        check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd(loop)")
+        self.d_dec.phase = 0
         htop = w["hs_d"][L - 1, 1:].reshape(self.Td * B, H)
         out = self.dec.out_layer
         ops.gemm(K_MAJOR, K_MAJOR, self.Td * B, V, H, htop, H, out.weight, H, w["logits"], V, bias=out.bias)
 
-    def _loss_and_backward(self, part: str = "all"):
-        """part: 'all', or 'dec' (loss + vocabulary projection + decoder backward) / 'rest'
-        (text + frame encoder backward) when the step is split so the decoder bucket's
-        all-reduce overlaps the encoders' backward."""
-        if part in ("all", "dec"):
-            self._backward_decoder()
-            if self.grad_hook:
-                self.grad_hook(self, "dec")
-        if part in ("all", "rest"):
-            self._backward_encoders()
-            if self.grad_hook:
-                self.grad_hook(self, "rest")
+    def _loss_and_backward(self):
+        lib, w = _lib.load(), self.ws
+        L, B, H, V, E = self.L, self.B, self.H, self.V, self.E
+        R = self.Td * B
+        s = ops._stream()
+        logits = w["logits"]
+        check(lib.mmqg_ce_fwd_bwd(logits.data_ptr(), V, w["target"].data_ptr(), w["row_w"].data_ptr(), R, V,
+                                  w["loss_rows"].data_ptr(), w["argmax"].data_ptr(), logits.data_ptr(), V, s), "ce_fwd_bwd")
+        check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), s), "reduce_sum")
+        out = self.dec.out_layer
+        htop = w["hs_d"][L - 1, 1:].reshape(R, H)
+        demb = self.dec.emb_layer.weight.grad
+        # vocabulary projection backward (logits now holds dlogits): weight gradient on the side stream
+        with self._fork():
+            ops.gemm(MN_MAJOR, MN_MAJOR, V, H, R, logits, V, htop, H, out.weight.grad, H, beta=1)
+            ops.colsum_add(logits, out.bias.grad)
+        ops.gemm(K_MAJOR, MN_MAJOR, R, H, V, logits, V, out.weight, H, w["dhtop"], H)
+        self.g_dec.phase = 1
+        check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s), "decoder_seq_bwd(loop)")
+        self._join()
+        with self._fork():
+            s2 = ops._stream()
+            self.g_dec.phase = 2
+            check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s2), "decoder_seq_bwd(wgrad)")
+            ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
+            self.g_vid.phase = 0
+            check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s2), "lstm_seq_bwd(frames)")
+        self.g_dec.phase = 0
+        self.g_text.phase = 1
+        check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, loop)")
+        self.g_text.phase = 2
+        check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, wgrad)")
+        self.g_text.phase = 0
+        ops.embedding_bwd(w["dxemb_c"].view(-1, E), w["ids_c"], demb)
+        self._join()
+        if self.grad_hook:
+            self.grad_hook(self, "all")
 
     def _refresh_transposes(self):
-        """k-major copies of the recurrent weights for the backward loops.  Done at the start of
-        every backward (9 small launches, ~45 MB moved) so externally loaded weights are honoured."""
+        """k-major copies of the recurrent weights for the backward loops, rebuilt every step
+        (9 small launches on the side stream) so externally loaded weights are honoured."""
         lib, s, w = _lib.load(), ops._stream(), self.ws
         H, L, Hv = self.H, self.L, self.Hv
 
@@ -355,32 +404,6 @@ class BatchedTrainer:
         In0 = self.E + self.Cw
         tr(self.dec.lstm.weight_ih_l0.data_ptr() + 4 * self.E, In0, 4 * H, self.Cw, w["wih0cT"], 4 * H)
         tr(self.dec.text_attn.weight.data_ptr() + 4 * self.E, self.E + H, self.S, H, w["wattn_hT"], self.ldS)
-
-    def _backward_decoder(self):
-        self._refresh_transposes()
-        lib, s, w = _lib.load(), ops._stream(), self.ws
-        L, B, H, V, E = self.L, self.B, self.H, self.V, self.E
-        R = self.Td * B
-        logits = w["logits"]
-        check(lib.mmqg_ce_fwd_bwd(logits.data_ptr(), V, w["target"].data_ptr(), w["row_w"].data_ptr(), R, V,
-                                  w["loss_rows"].data_ptr(), w["argmax"].data_ptr(), logits.data_ptr(), V, s), "ce_fwd_bwd")
-        check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), s), "reduce_sum")
-        out = self.dec.out_layer
-        htop = w["hs_d"][L - 1, 1:].reshape(R, H)
-        # vocabulary projection backward (logits now holds dlogits)
-        ops.gemm(K_MAJOR, MN_MAJOR, R, H, V, logits, V, out.weight, H, w["dhtop"], H)
-        ops.gemm(MN_MAJOR, MN_MAJOR, V, H, R, logits, V, htop, H, out.weight.grad, H, beta=1)
-        ops.colsum_add(logits, out.bias.grad)
-        check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s), "decoder_seq_bwd")
-        demb = self.dec.emb_layer.weight.grad
-        ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
-
-    def _backward_encoders(self):
-        lib, s, w, E = _lib.load(), ops._stream(), self.ws, self.E
-        demb = self.dec.emb_layer.weight.grad
-        check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text)")
-        ops.embedding_bwd(w["dxemb_c"].view(-1, E), w["ids_c"], demb)
-        check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s), "lstm_seq_bwd(frames)")
 
     def _adam(self):
         lib, s = _lib.load(), ops._stream()
@@ -413,9 +436,7 @@ class BatchedTrainer:
                 feats = self.video.cnn_features(raw, self.ws["n_frames"]).transpose(0, 1).contiguous()
             self.ws["feats"].copy_(feats.detach())
         self._forward(self.training)
-        self._loss_and_backward("dec")
-        self.reducer.reduce("dec")                 # overlaps the encoders' backward (no-op on 1 GPU)
-        self._loss_and_backward("rest")
+        self._loss_and_backward()
         if feats is not None:
             feats.backward(self.ws["dfeats"])
         return self.ws["loss"]
@@ -425,43 +446,35 @@ class BatchedTrainer:
         if self.use_graph and batch is not None and batch["frames"].dim() != 5:
             return self._graph_step(batch)
         loss = self.forward_backward(batch)
-        self.reducer.reduce("rest")
-        self.reducer.finish()
+        self._allreduce()
         self._adam()
         return loss
 
     # ------------------------------------------------------------------------ hipGraph
-    def _graph_body(self, part: str):
-        if part == "dec":
-            self.flat_g.zero_()
-            self._forward(True)
-        self._loss_and_backward(part)
+    def _graph_body(self):
+        self.flat_g.zero_()
+        self._forward(True)
+        self._loss_and_backward()
 
     def _graph_step(self, batch):
         self.load_batch(batch)
         if self._graph is None:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):      # warm-up outside capture (lazy code-object loads)
-                self._graph_body("dec")
-                self._graph_body("rest")
-            torch.cuda.current_stream().wait_stream(side)
-            # three graphs: [zero, forward, loss, decoder backward] | [encoder backward] | [Adam];
-            # the gradient all-reduces sit between them (RCCL is not captured)
+            warm = torch.cuda.Stream()
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):      # warm-up outside capture (lazy code-object loads)
+                self._graph_body()
+            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.synchronize()
+            # two graphs: [zero, forward, loss, backward] (with its internal fork/join branches) and
+            # [Adam]; the gradient all-reduce sits between them (RCCL is not captured)
             self._graph = torch.cuda.CUDAGraph()
-            self._graph_rest = torch.cuda.CUDAGraph()
             self._graph_adam = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._graph_body("dec")
-            with torch.cuda.graph(self._graph_rest, pool=self._graph.pool()):
-                self._graph_body("rest")
+                self._graph_body()
             with torch.cuda.graph(self._graph_adam, pool=self._graph.pool()):
                 self._adam()
         self._graph.replay()
-        self.reducer.reduce("dec")
-        self._graph_rest.replay()
-        self.reducer.reduce("rest")
-        self.reducer.finish()
+        self._allreduce()
         self._graph_adam.replay()
         return self.ws["loss"]
 
