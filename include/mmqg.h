@@ -153,6 +153,8 @@ typedef struct {
     const float* b_hh[MMQG_MAX_LAYERS];
     const float* w_hhT[MMQG_MAX_LAYERS];            /* optional [H][4H] transposed copies: enable the
                                                        fused one-launch-per-layer-step backward */
+    const float* w_ihT[MMQG_MAX_LAYERS];            /* optional [H][4H] for l >= 1: with w_hhT, a multi-layer
+                                                       backward runs as a wavefront over (layer, time) diagonals */
     const float* h0; const float* c0;               /* [L][B][H] or NULL = zeros */
     const int32_t* lens;                            /* [B] or NULL */
     float dropout_p; int32_t training; uint64_t seed; uint64_t stream_base;
@@ -168,7 +170,7 @@ typedef struct {
     const float* dhT; const float* dcT;             /* [L][B][H] grad of the final state, nullable */
     float* dgates;                                  /* [L][T][B][4H] scratch */
     float* dxl;                                     /* [T][B][H] scratch */
-    float* dh; float* dc;                           /* [B][H] scratch */
+    float* dh; float* dc;                           /* [L][B][H] scratch */
     float* dx; int32_t lddx;                        /* [T][B][In] out, nullable */
     float* dw_ih[MMQG_MAX_LAYERS]; float* dw_hh[MMQG_MAX_LAYERS];
     float* db_ih[MMQG_MAX_LAYERS]; float* db_hh[MMQG_MAX_LAYERS];

@@ -40,6 +40,7 @@ class LstmSeq(C.Structure):
     _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("In", C.c_int32),
                 ("x", c_f), ("ldx", C.c_int32),
                 ("w_ih", _PTRS), ("w_hh", _PTRS), ("b_ih", _PTRS), ("b_hh", _PTRS), ("w_hhT", _PTRS),
+                ("w_ihT", _PTRS),
                 ("h0", c_f), ("c0", c_f), ("lens", c_f),
                 ("dropout_p", c_fl), ("training", C.c_int32), ("seed", c_u64), ("stream_base", c_u64),
                 ("seed_offset", c_f),

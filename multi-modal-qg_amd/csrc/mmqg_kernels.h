@@ -62,6 +62,11 @@ int skinny_cell_fwd(const SkinnyPair* pairs, int npairs, int gates_has_pre, cons
                     const CellFwd& f, hipStream_t s);
 // dh(t) = sum of pairs + carry (f.dh_rec) [+ above, extra], then the cell backward of CellBwd
 int skinny_cell_bwd(const SkinnyPair* pairs, int npairs, const CellBwd& f, hipStream_t s);
+// up to three independent layer-steps (one wavefront diagonal of a layer stack) in ONE launch
+struct SkinnyFwdJob { SkinnyPair pairs[3]; int npairs; int gates_has_pre; const float* bias1; const float* bias2; CellFwd cell; };
+struct SkinnyBwdJob { SkinnyPair pairs[3]; int npairs; CellBwd cell; };
+int skinny_cell_fwd_multi(const SkinnyFwdJob* jobs, int njobs, hipStream_t s);
+int skinny_cell_bwd_multi(const SkinnyBwdJob* jobs, int njobs, hipStream_t s);
 int transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s);
 
 // ---- attention.hip --------------------------------------------------------------------

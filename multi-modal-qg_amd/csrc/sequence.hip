@@ -38,6 +38,12 @@ int check_lstm(const mmqg_lstm_seq& d, const char* who) {
 
 inline bool lstm_drop(const mmqg_lstm_seq& d) { return d.training && d.dropout_p > 0.f && d.L > 1; }
 
+// MMQG_NO_WAVEFRONT=1: layer-by-layer time loops (one fused launch per layer-step) for A/B comparisons
+inline bool g_no_wavefront() {
+    static const bool v = [] { const char* e = getenv("MMQG_NO_WAVEFRONT"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 // MMQG_NO_FUSE=1 keeps the round-1 path (tiled GEMM + separate cell kernels) for A/B comparisons
 inline bool g_no_fuse() {
     static const bool v = [] { const char* e = getenv("MMQG_NO_FUSE"); return e && atoi(e) != 0; }();
@@ -48,9 +54,75 @@ inline bool g_no_fuse() {
 
 namespace mmqg {
 
+// Forward of a layer stack as a wavefront: diagonal s runs layer l at time t = s - l for every l,
+// up to three independent layer-steps in ONE launch (T + L - 1 dependent launches instead of L*T).
+// Layers >= 1 take their input product in the same launch (x*W_ih^T + h*W_hh^T + biases).
+static int lstm_seq_fwd_wavefront(const mmqg_lstm_seq& d, hipStream_t s) {
+    const int T = d.T, B = d.B, H = d.H, L = d.L;
+    const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
+    const bool drop = lstm_drop(d);
+    for (int l = 0; l < L; ++l) {
+        MMQG_TRY(copy_or_zero(d.hs + (int64_t)l * (T + 1) * BH, d.h0 ? d.h0 + l * BH : nullptr, (size_t)BH, s));
+        MMQG_TRY(copy_or_zero(d.cs + (int64_t)l * (T + 1) * BH, d.c0 ? d.c0 + l * BH : nullptr, (size_t)BH, s));
+    }
+    // layer 0: every input product at once
+    MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, 4 * H, d.In, d.x, d.ldx, d.w_ih[0], d.In, nullptr, 0, nullptr, 0, 0,
+                      d.b_ih[0], d.b_hh[0], 0, d.gates, 4 * H, -1, s));
+    for (int diag = 0; diag < T + L - 1; ++diag) {
+        SkinnyFwdJob jobs[3];
+        int nj = 0;
+        for (int l = 0; l < L; ++l) {
+            const int t = diag - l;
+            if (t < 0 || t >= T) continue;
+            float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
+            float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
+            SkinnyFwdJob& j = jobs[nj++];
+            j = SkinnyFwdJob{};
+            if (l == 0) {
+                j.pairs[0] = SkinnyPair{hs_l + t * BH, H, d.w_hh[0], H, H, 0};
+                j.npairs = 1; j.gates_has_pre = 1;
+            } else {
+                const float* xin = drop ? d.hdrop + (int64_t)(l - 1) * T * BH + t * BH
+                                        : d.hs + (int64_t)(l - 1) * (T + 1) * BH + (t + 1) * BH;
+                j.pairs[0] = SkinnyPair{xin, H, d.w_ih[l], H, H, 0};
+                j.pairs[1] = SkinnyPair{hs_l + t * BH, H, d.w_hh[l], H, H, 0};
+                j.npairs = 2; j.gates_has_pre = 0; j.bias1 = d.b_ih[l]; j.bias2 = d.b_hh[l];
+            }
+            CellFwd& c = j.cell;
+            c.B = B; c.H = H; c.gates = d.gates + (int64_t)l * T * G + t * G; c.ld_g = 4 * H;
+            c.h_prev = hs_l + t * BH; c.c_prev = cs_l + t * BH;
+            c.h_out = hs_l + (t + 1) * BH; c.c_out = cs_l + (t + 1) * BH;
+            c.h_drop = (drop && l < L - 1) ? d.hdrop + (int64_t)l * T * BH + t * BH : nullptr;
+            c.y_out = (l == L - 1 && d.y) ? d.y + t * d.y_stride_t : nullptr;
+            c.y_stride_b = d.y_stride_b;
+            c.lens = d.lens; c.t = t;
+            c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
+            if (nj == 3 || l == L - 1) { MMQG_TRY(skinny_cell_fwd_multi(jobs, nj, s)); nj = 0; }
+        }
+        if (nj > 0) MMQG_TRY(skinny_cell_fwd_multi(jobs, nj, s));
+    }
+    return 0;
+}
+
+static bool lstm_wavefront_fwd_ok(const mmqg_lstm_seq& d) {
+    if (d.L < 2 || d.T < 1 || d.H % 4 != 0 || g_no_fuse() || g_no_wavefront()) return false;
+    const int H = d.H;
+    for (int l = 0; l < d.L; ++l) {
+        const SkinnyPair a{d.hs, H, d.w_hh[l], H, H, 0};
+        if (!skinny_usable(&a, 1)) return false;
+        if (l > 0) {
+            const SkinnyPair b{d.hs, H, d.w_ih[l], H, H, 0};
+            if (!skinny_usable(&b, 1)) return false;
+            if (lstm_drop(d) && !mmqg::aligned16(d.hdrop)) return false;
+        }
+    }
+    return true;
+}
+
 int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s) {
     MMQG_TRY(check_lstm(d, "lstm_seq_fwd"));
     if (d.B == 0) return 0;
+    if (lstm_wavefront_fwd_ok(d)) return lstm_seq_fwd_wavefront(d, s);
     const int T = d.T, B = d.B, H = d.H, L = d.L;
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
     const bool drop = lstm_drop(d);
@@ -94,6 +166,73 @@ int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s) {
     return 0;
 }
 
+// Backward time loops of a layer stack as a wavefront over (layer, time) anti-diagonals: layer l at
+// time t needs dgates_l(t+1) (recurrent) and dgates_{l+1}(t) (gradient of its output as the input of
+// the layer above, through this layer's dropout mask) — both from the previous diagonal.
+static int lstm_seq_bwd_wavefront(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s) {
+    const int T = d.T, B = d.B, H = d.H, L = d.L;
+    const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
+    const bool drop = lstm_drop(d);
+    for (int l = 0; l < L; ++l) {
+        MMQG_TRY(copy_or_zero(g.dh + l * BH, g.dhT ? g.dhT + l * BH : nullptr, (size_t)BH, s));
+        MMQG_TRY(copy_or_zero(g.dc + l * BH, g.dcT ? g.dcT + l * BH : nullptr, (size_t)BH, s));
+    }
+    for (int diag = 0; diag < T + L - 1; ++diag) {
+        SkinnyBwdJob jobs[3];
+        int nj = 0;
+        for (int l = L - 1; l >= 0; --l) {
+            const int t = (T - 1) - (diag - (L - 1 - l));
+            if (t < 0 || t >= T) continue;
+            const float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
+            SkinnyBwdJob j{};
+            if (t < T - 1)
+                j.pairs[j.npairs++] = SkinnyPair{g.dgates + (int64_t)l * T * G + (t + 1) * G, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+            if (l < L - 1)
+                j.pairs[j.npairs++] = SkinnyPair{g.dgates + (int64_t)(l + 1) * T * G + t * G, 4 * H, d.w_ihT[l + 1], 4 * H, 4 * H, 1};
+            CellBwd& c = j.cell;
+            c.B = B; c.H = H; c.gates_act = d.gates + (int64_t)l * T * G + t * G;
+            c.c_prev = cs_l + t * BH; c.c_new = cs_l + (t + 1) * BH;
+            c.dh_rec = g.dh + l * BH;
+            if (l < L - 1) {
+                c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
+            } else if (g.dy) {
+                c.dh_extra = g.dy + t * g.dy_stride_t; c.extra_stride_b = g.dy_stride_b;
+            }
+            c.dc = g.dc + l * BH; c.dgates = g.dgates + (int64_t)l * T * G + t * G; c.ld_dg = 4 * H;
+            c.lens = d.lens; c.t = t;
+            if (j.npairs == 0) { MMQG_TRY(lstm_cell_bwd(c, s)); continue; }     // top layer, last step
+            jobs[nj++] = j;
+            if (nj == 3) { MMQG_TRY(skinny_cell_bwd_multi(jobs, nj, s)); nj = 0; }
+        }
+        if (nj > 0) MMQG_TRY(skinny_cell_bwd_multi(jobs, nj, s));
+    }
+    if (g.dh0 || g.dc0) {
+        for (int l = 0; l < L; ++l) {
+            if (g.dh0) {   // gradient of the initial state: carry + dgates_l(0) * W_hh_l
+                const SkinnyPair pr{g.dgates + (int64_t)l * T * G, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+                MMQG_TRY(skinny_plain(B, H, &pr, 1, nullptr, 1, g.dh + l * BH, H, s));
+                MMQG_TRY(copy_or_zero(g.dh0 + l * BH, g.dh + l * BH, (size_t)BH, s));
+            }
+            if (g.dc0) MMQG_TRY(copy_or_zero(g.dc0 + l * BH, g.dc + l * BH, (size_t)BH, s));
+        }
+    }
+    return 0;
+}
+
+static bool lstm_wavefront_bwd_ok(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g) {
+    if (d.L < 2 || d.L > 3 || g_no_fuse() || g_no_wavefront()) return false;
+    const int H = d.H;
+    for (int l = 0; l < d.L; ++l) {
+        const SkinnyPair a{g.dgates, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+        if (!d.w_hhT[l] || !skinny_usable(&a, 1)) return false;
+        if (l > 0) {
+            const SkinnyPair b{g.dgates, 4 * H, d.w_ihT[l], 4 * H, 4 * H, 1};
+            if (!d.w_ihT[l] || !skinny_usable(&b, 1)) return false;
+        }
+    }
+    return true;
+}
+
 int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s) {
     MMQG_TRY(check_lstm(d, "lstm_seq_bwd"));
     if (d.B == 0 || d.T == 0) return 0;
@@ -104,7 +243,12 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
     const bool drop = lstm_drop(d);
     MMQG_REQUIRE(g.phase >= 0 && g.phase <= 2, "lstm_seq_bwd: phase must be 0, 1 or 2");
-    const bool do_loop = g.phase != 2, do_wgrad = g.phase != 1;
+    const bool do_wgrad = g.phase != 1;
+    bool do_loop = g.phase != 2;
+    if (do_loop && lstm_wavefront_bwd_ok(d, g)) {
+        MMQG_TRY(lstm_seq_bwd_wavefront(d, g, s));
+        do_loop = false;
+    }
     for (int l = L - 1; l >= 0 && do_loop; --l) {
         const float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
         const float* gates_l = d.gates + (int64_t)l * T * G;

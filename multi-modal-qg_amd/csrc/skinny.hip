@@ -21,6 +21,8 @@
 // optimizer step by transpose_f32) so that every B operand is k-major too.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "mmqg_common.h"
 #include "mmqg_kernels.h"
 
@@ -63,9 +65,16 @@ __device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const int32_t* off) 
     return off ? seed + (uint64_t)(uint32_t)off[0] * 0x9E3779B97F4A7C15ull : seed;
 }
 
+struct SkinnyBatch {
+    SkinnyK job[3];      // blockIdx.z selects the job: independent layer-steps of one wavefront diagonal
+};
+
 template <int MODE, int KS>
-__global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyK a) {
+__global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
     __shared__ float part[2][KS][16][17];
+    const SkinnyK& a = batch.job[blockIdx.z];
+    if ((int)blockIdx.y * 16 >= a.M || (int)blockIdx.x * (MODE == MODE_FWD_CELL ? 4 : 16) >= (MODE == MODE_FWD_CELL ? a.H : a.N))
+        return;   // jobs of one launch may differ in size
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, kq = lane >> 4;      // MFMA operand slot of this lane: tile row/col c, k-slot kq
     const int m0 = blockIdx.y * 16;
@@ -296,13 +305,28 @@ bool pair_ok(const mmqg::SkinnyPair& p) {
 }
 
 template <int MODE>
-int launch_skinny(const SkinnyK& k, int tiles_n, hipStream_t s, const char* what) {
-    dim3 grid(tiles_n, mmqg::ceil_div(k.M, 16));
+int launch_skinny_batch(const SkinnyBatch& b, int njobs, hipStream_t s, const char* what) {
+    int tiles_n = 0, tiles_m = 0, chunks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const SkinnyK& k = b.job[i];
+        tiles_n = std::max(tiles_n, MODE == MODE_FWD_CELL ? k.H / 4 : mmqg::ceil_div(k.N, 16));
+        tiles_m = std::max(tiles_m, mmqg::ceil_div(k.M, 16));
+        chunks = std::max(chunks, k.chunks);
+    }
+    dim3 grid(tiles_n, tiles_m, njobs);
     // enough K per wave to amortise the reduction; 8 waves once a tile has >= 64 chunks
     static const int ks8_from = [] { const char* e = getenv("MMQG_SKINNY_KS8_FROM"); return e ? atoi(e) : 64; }();
-    if (k.chunks >= ks8_from) hipLaunchKernelGGL((skinny_kernel<MODE, 8>), grid, dim3(512), 0, s, k);
-    else hipLaunchKernelGGL((skinny_kernel<MODE, 4>), grid, dim3(256), 0, s, k);
+    if (chunks >= ks8_from) hipLaunchKernelGGL((skinny_kernel<MODE, 8>), grid, dim3(512), 0, s, b);
+    else hipLaunchKernelGGL((skinny_kernel<MODE, 4>), grid, dim3(256), 0, s, b);
     return mmqg::check_launch(what);
+}
+
+template <int MODE>
+int launch_skinny(const SkinnyK& k, int tiles_n, hipStream_t s, const char* what) {
+    (void)tiles_n;
+    SkinnyBatch b{};
+    b.job[0] = k;
+    return launch_skinny_batch<MODE>(b, 1, s, what);
 }
 
 int fill_pairs(SkinnyK& k, const mmqg::SkinnyPair* pairs, int npairs, const char* who) {
@@ -344,33 +368,63 @@ int skinny_plain(int M, int N, const SkinnyPair* pairs, int npairs, const float*
     return launch_skinny<MODE_PLAIN>(k, ceil_div(N, 16), s, "skinny_plain");
 }
 
-int skinny_cell_fwd(const SkinnyPair* pairs, int npairs, int gates_has_pre, const float* bias1, const float* bias2,
-                    const CellFwd& f, hipStream_t s) {
-    MMQG_REQUIRE(f.B >= 0 && f.H > 0 && f.H % 4 == 0 && f.ld_g == 4 * f.H, "skinny_cell_fwd: need H %% 4 == 0 and compact gates");
-    if (f.B == 0) return 0;
+static int fill_fwd_job(SkinnyK& k, const SkinnyFwdJob& j) {
+    const CellFwd& f = j.cell;
+    MMQG_REQUIRE(f.B > 0 && f.H > 0 && f.H % 4 == 0 && f.ld_g == 4 * f.H, "skinny_cell_fwd: need H %% 4 == 0 and compact gates");
     MMQG_REQUIRE(f.gates && f.h_prev && f.c_prev && f.h_out && f.c_out, "skinny_cell_fwd: null pointer");
-    SkinnyK k{};
-    MMQG_TRY(fill_pairs(k, pairs, npairs, "skinny_cell_fwd"));
+    MMQG_TRY(fill_pairs(k, j.pairs, j.npairs, "skinny_cell_fwd"));
     k.M = f.B; k.N = 4 * f.H; k.H = f.H;
     k.lens = f.lens; k.t = f.t; k.drop_p = f.p; k.seed = f.seed; k.stream_id = f.stream_id; k.seed_off = f.seed_off;
-    k.gates = f.gates; k.gates_has_pre = gates_has_pre; k.bias1 = bias1; k.bias2 = bias2;
+    k.gates = f.gates; k.gates_has_pre = j.gates_has_pre; k.bias1 = j.bias1; k.bias2 = j.bias2;
     k.h_prev = f.h_prev; k.c_prev = f.c_prev; k.h_out = f.h_out; k.c_out = f.c_out; k.h_drop = f.h_drop;
     k.y_out = f.y_out; k.y_stride_b = f.y_stride_b;
-    return launch_skinny<MODE_FWD_CELL>(k, f.H / 4, s, "skinny_cell_fwd");
+    return 0;
 }
 
-int skinny_cell_bwd(const SkinnyPair* pairs, int npairs, const CellBwd& f, hipStream_t s) {
-    MMQG_REQUIRE(f.B >= 0 && f.H > 0 && f.ld_dg == 4 * f.H, "skinny_cell_bwd: need compact dgates");
-    if (f.B == 0) return 0;
+static int fill_bwd_job(SkinnyK& k, const SkinnyBwdJob& j) {
+    const CellBwd& f = j.cell;
+    MMQG_REQUIRE(f.B > 0 && f.H > 0 && f.ld_dg == 4 * f.H, "skinny_cell_bwd: need compact dgates");
     MMQG_REQUIRE(f.gates_act && f.c_prev && f.c_new && f.dh_rec && f.dc && f.dgates, "skinny_cell_bwd: null pointer");
-    SkinnyK k{};
-    MMQG_TRY(fill_pairs(k, pairs, npairs, "skinny_cell_bwd"));
+    MMQG_TRY(fill_pairs(k, j.pairs, j.npairs, "skinny_cell_bwd"));
     k.M = f.B; k.N = f.H; k.H = f.H;
     k.lens = f.lens; k.t = f.t; k.drop_p = f.p; k.seed = f.seed; k.stream_id = f.stream_id; k.seed_off = f.seed_off;
     k.gates_act = f.gates_act; k.c_prev = f.c_prev; k.c_new = f.c_new; k.carry = f.dh_rec;
     k.above = f.dh_above; k.above_stride_b = f.above_stride_b; k.extra = f.dh_extra; k.extra_stride_b = f.extra_stride_b;
     k.dc = f.dc; k.dgates = f.dgates;
-    return launch_skinny<MODE_BWD_CELL>(k, ceil_div(f.H, 16), s, "skinny_cell_bwd");
+    return 0;
+}
+
+int skinny_cell_fwd_multi(const SkinnyFwdJob* jobs, int njobs, hipStream_t s) {
+    MMQG_REQUIRE(njobs >= 1 && njobs <= 3, "skinny_cell_fwd_multi: 1..3 jobs");
+    SkinnyBatch b{};
+    for (int i = 0; i < njobs; ++i) MMQG_TRY(fill_fwd_job(b.job[i], jobs[i]));
+    return launch_skinny_batch<MODE_FWD_CELL>(b, njobs, s, "skinny_cell_fwd");
+}
+
+int skinny_cell_bwd_multi(const SkinnyBwdJob* jobs, int njobs, hipStream_t s) {
+    MMQG_REQUIRE(njobs >= 1 && njobs <= 3, "skinny_cell_bwd_multi: 1..3 jobs");
+    SkinnyBatch b{};
+    for (int i = 0; i < njobs; ++i) MMQG_TRY(fill_bwd_job(b.job[i], jobs[i]));
+    return launch_skinny_batch<MODE_BWD_CELL>(b, njobs, s, "skinny_cell_bwd");
+}
+
+int skinny_cell_fwd(const SkinnyPair* pairs, int npairs, int gates_has_pre, const float* bias1, const float* bias2,
+                    const CellFwd& f, hipStream_t s) {
+    if (f.B == 0) return 0;
+    MMQG_REQUIRE(npairs >= 1 && npairs <= 3, "skinny_cell_fwd: need 1..3 operand pairs");
+    SkinnyFwdJob j{};
+    for (int i = 0; i < npairs; ++i) j.pairs[i] = pairs[i];
+    j.npairs = npairs; j.gates_has_pre = gates_has_pre; j.bias1 = bias1; j.bias2 = bias2; j.cell = f;
+    return skinny_cell_fwd_multi(&j, 1, s);
+}
+
+int skinny_cell_bwd(const SkinnyPair* pairs, int npairs, const CellBwd& f, hipStream_t s) {
+    if (f.B == 0) return 0;
+    MMQG_REQUIRE(npairs >= 1 && npairs <= 3, "skinny_cell_bwd: need 1..3 operand pairs");
+    SkinnyBwdJob j{};
+    for (int i = 0; i < npairs; ++i) j.pairs[i] = pairs[i];
+    j.npairs = npairs; j.cell = f;
+    return skinny_cell_bwd_multi(&j, 1, s);
 }
 
 int transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s) {

@@ -288,8 +288,8 @@ class LSTMSeqFn(torch.autograd.Function):
         g.dhT, g.dcT = ptr(dhT), ptr(dcT)
         dgates = torch.empty(L, T, B, 4 * H, device=dev, dtype=torch.float32)
         dxl = torch.empty(T, B, H, device=dev, dtype=torch.float32)
-        dh = torch.empty(B, H, device=dev, dtype=torch.float32)
-        dc = torch.empty(B, H, device=dev, dtype=torch.float32)
+        dh = torch.empty(L, B, H, device=dev, dtype=torch.float32)
+        dc = torch.empty(L, B, H, device=dev, dtype=torch.float32)
         dx = torch.empty(T, B, In, device=dev, dtype=torch.float32)
         dh0 = torch.empty(L, B, H, device=dev, dtype=torch.float32)
         dc0 = torch.empty(L, B, H, device=dev, dtype=torch.float32)

@@ -176,12 +176,13 @@ class BatchedTrainer:
         w["dh_d"], w["dc_d"], w["dxa"] = f(L, B, H), f(L, B, H), f(L, B, H)
         w["dxemb_d"] = f(Td, B, E)
         w["dtext"], w["dvideo"] = f(Tc, B, H), f(Tf, B, Hv)
-        w["dgates_t"], w["dxl_t"], w["dh_t"], w["dc_t"] = f(L, Tc, B, 4 * H), f(Tc, B, H), f(B, H), f(B, H)
+        w["dgates_t"], w["dxl_t"], w["dh_t"], w["dc_t"] = f(L, Tc, B, 4 * H), f(Tc, B, H), f(L, B, H), f(L, B, H)
         w["dxemb_c"] = f(Tc, B, E)
         w["dgates_v"], w["dh_v"], w["dc_v"], w["dfeats"] = f(1, Tf, B, 4 * Hv), f(B, Hv), f(B, Hv), f(Tf, B, Fin)
         # k-major (transposed) copies of the recurrent weights for the fused backward time loops
         w["whhT_v"] = f(1, Hv, 4 * Hv)
         w["whhT_t"], w["whhT_d"], w["wihT_d"] = f(L, H, 4 * H), f(L, H, 4 * H), f(L, H, 4 * H)
+        w["wihT_t"] = f(L, H, 4 * H)
         w["wih0cT"], w["wattn_hT"] = f(Cw, 4 * H), f(H, ldS)
 
     # ----------------------------------------------------------------------- descriptors
@@ -227,6 +228,8 @@ class BatchedTrainer:
         gt.dx, gt.lddx = w["dxemb_c"].data_ptr(), self.E
         for l in range(L):
             dt.w_hhT[l] = w["whhT_t"][l].data_ptr()
+            if l > 0:
+                dt.w_ihT[l] = w["wihT_t"][l].data_ptr()
         self.d_text, self.g_text = dt, gt
         # decoder
         dd, gd = _lib.DecoderSeq(), _lib.DecoderSeqGrad()
@@ -401,6 +404,7 @@ class BatchedTrainer:
             tr(getattr(self.dec.lstm, f"weight_hh_l{l}").data_ptr(), H, 4 * H, H, w["whhT_d"][l], 4 * H)
             if l > 0:
                 tr(getattr(self.dec.lstm, f"weight_ih_l{l}").data_ptr(), H, 4 * H, H, w["wihT_d"][l], 4 * H)
+                tr(getattr(self.text.lstm, f"weight_ih_l{l}").data_ptr(), H, 4 * H, H, w["wihT_t"][l], 4 * H)
         In0 = self.E + self.Cw
         tr(self.dec.lstm.weight_ih_l0.data_ptr() + 4 * self.E, In0, 4 * H, self.Cw, w["wih0cT"], 4 * H)
         tr(self.dec.text_attn.weight.data_ptr() + 4 * self.E, self.E + H, self.S, H, w["wattn_hT"], self.ldS)
