@@ -19,6 +19,8 @@
 // through LDS.  Backward: one workgroup per (question, modality, 32-row block), one
 // wavefront per row at a time, lanes across the row's columns (whole contiguous rows),
 // shuffle reduction per row.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "mmqg_common.h"
@@ -26,7 +28,6 @@
 
 namespace {
 
-constexpr int kChunk = 128;      // value columns per forward workgroup
 constexpr int kMaxRows = 4096;   // longest score segment the LDS weight buffer holds
 constexpr int kRowBlock = 32;    // value rows per backward workgroup
 
@@ -84,10 +85,12 @@ struct AttnFwdK {
     int vec_text, vec_audio, vec_video;
 };
 
+template <int kChunk>   // value columns per workgroup: 256 threads = (kChunk/4) float4 column lanes x row groups
 __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK a) {
+    constexpr int kLanes = kChunk / 4, kGroups = 256 / kLanes;
     __shared__ float w[kMaxRows];
-    __shared__ __attribute__((aligned(16))) float red[8 * kChunk];
-    __shared__ float sh[4];
+    __shared__ __attribute__((aligned(16))) float red[kGroups * kChunk];
+    __shared__ float sh[8];
 
     const int b = blockIdx.y;
     int chunk = blockIdx.x, modality = 0;
@@ -98,7 +101,25 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
     const int tid = threadIdx.x;
     const bool masked = a.v.mask_mode == MMQG_MASK_INTENDED;
 
-    // ---- softmax of the score segment (every chunk of the segment recomputes it; L <= a few hundred)
+    // ---- this thread's slice of the value stream: column lane cl (float4), row group rg
+    const int cl = tid % kLanes, rg = tid / kLanes;
+    const int col = chunk * kChunk + 4 * cl;
+    const bool col_ok = col < sg.D;
+    const float* V = sg.base + col;
+    // The first four rows are requested BEFORE the softmax so their HBM latency hides behind it
+    // (a launch is ~10 us: the fixed prologue matters as much as the streaming rate).
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+    const int i0 = rg, i1 = rg + kGroups, i2 = rg + 2 * kGroups, i3 = rg + 3 * kGroups;
+    if (vec && col_ok) {
+        if (i0 < sg.L) p0 = *reinterpret_cast<const float4*>(V + (int64_t)i0 * sg.D);
+        if (i1 < sg.L) p1 = *reinterpret_cast<const float4*>(V + (int64_t)i1 * sg.D);
+        if (i2 < sg.L) p2 = *reinterpret_cast<const float4*>(V + (int64_t)i2 * sg.D);
+        if (i3 < sg.L) p3 = *reinterpret_cast<const float4*>(V + (int64_t)i3 * sg.D);
+    }
+
+    // ---- softmax of the score segment (every chunk of the segment recomputes it; L <= a few hundred).
+    // w[] keeps the UNNORMALISED exp(s - max); the row sum only scales the final context, so the
+    // value stream does not wait for it.  Two barriers before the stream, one after.
     const float* srow = a.scores + (int64_t)b * a.ld_s + sg.seg_off;
     float lmax = -INFINITY;
     for (int i = tid; i < sg.L; i += 256) {
@@ -107,48 +128,56 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
         w[i] = s;
         lmax = fmaxf(lmax, s);
     }
-    const float m = block_max(lmax, sh);
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) sh[tid >> 6] = lmax;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     float lsum = 0.f;
     for (int i = tid; i < sg.L; i += 256) {
-        const float e = expf(w[i] - m);
+        const float e = expf(w[i] - m);      // own element: written by this thread above
         w[i] = e;
         lsum += e;
     }
-    const float inv = 1.0f / block_sum(lsum, sh);
-    float* arow = a.attn + (int64_t)b * a.ld_a + sg.seg_off;
-    for (int i = tid; i < sg.L; i += 256) {
-        const float p = w[i] * inv;
-        w[i] = p;
-        if (chunk == 0) arow[i] = p;
-    }
+    lsum = wave_sum(lsum);
+    if ((tid & 63) == 0) sh[4 + (tid >> 6)] = lsum;
     __syncthreads();
+    const float inv = 1.0f / (sh[4] + sh[5] + sh[6] + sh[7]);
+    if (chunk == 0) {
+        float* arow = a.attn + (int64_t)b * a.ld_a + sg.seg_off;
+        for (int i = tid; i < sg.L; i += 256) arow[i] = w[i] * inv;
+    }
 
-    // ---- weighted row sum over this workgroup's 128 columns
-    const int cl = tid & 31, rg = tid >> 5;
-    const int col = chunk * kChunk + 4 * cl;
+    // ---- weighted row sum over this workgroup's kChunk columns
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-    if (col < sg.D) {
-        const float* V = sg.base + col;
+    if (col_ok) {
         if (vec) {
-            int i = rg;
-            for (; i + 24 < sg.L; i += 32) {
+            {
+                const float w0 = i0 < sg.L ? w[i0] : 0.f, w1 = i1 < sg.L ? w[i1] : 0.f;
+                const float w2 = i2 < sg.L ? w[i2] : 0.f, w3 = i3 < sg.L ? w[i3] : 0.f;
+                acc0.x += w0 * p0.x; acc0.y += w0 * p0.y; acc0.z += w0 * p0.z; acc0.w += w0 * p0.w;
+                acc1.x += w1 * p1.x; acc1.y += w1 * p1.y; acc1.z += w1 * p1.z; acc1.w += w1 * p1.w;
+                acc0.x += w2 * p2.x; acc0.y += w2 * p2.y; acc0.z += w2 * p2.z; acc0.w += w2 * p2.w;
+                acc1.x += w3 * p3.x; acc1.y += w3 * p3.y; acc1.z += w3 * p3.z; acc1.w += w3 * p3.w;
+            }
+            int i = rg + 4 * kGroups;
+            for (; i + 3 * kGroups < sg.L; i += 4 * kGroups) {
                 const float4 x0 = *reinterpret_cast<const float4*>(V + (int64_t)(i) * sg.D);
-                const float4 x1 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 8) * sg.D);
-                const float4 x2 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 16) * sg.D);
-                const float4 x3 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 24) * sg.D);
-                const float w0 = w[i], w1 = w[i + 8], w2 = w[i + 16], w3 = w[i + 24];
+                const float4 x1 = *reinterpret_cast<const float4*>(V + (int64_t)(i + kGroups) * sg.D);
+                const float4 x2 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 2 * kGroups) * sg.D);
+                const float4 x3 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 3 * kGroups) * sg.D);
+                const float w0 = w[i], w1 = w[i + kGroups], w2 = w[i + 2 * kGroups], w3 = w[i + 3 * kGroups];
                 acc0.x += w0 * x0.x; acc0.y += w0 * x0.y; acc0.z += w0 * x0.z; acc0.w += w0 * x0.w;
                 acc1.x += w1 * x1.x; acc1.y += w1 * x1.y; acc1.z += w1 * x1.z; acc1.w += w1 * x1.w;
                 acc0.x += w2 * x2.x; acc0.y += w2 * x2.y; acc0.z += w2 * x2.z; acc0.w += w2 * x2.w;
                 acc1.x += w3 * x3.x; acc1.y += w3 * x3.y; acc1.z += w3 * x3.z; acc1.w += w3 * x3.w;
             }
-            for (; i < sg.L; i += 8) {
+            for (; i < sg.L; i += kGroups) {
                 const float4 x0 = *reinterpret_cast<const float4*>(V + (int64_t)i * sg.D);
                 const float w0 = w[i];
                 acc0.x += w0 * x0.x; acc0.y += w0 * x0.y; acc0.z += w0 * x0.z; acc0.w += w0 * x0.w;
             }
         } else {
-            for (int i = rg; i < sg.L; i += 8) {
+            for (int i = rg; i < sg.L; i += kGroups) {
                 const float* r = V + (int64_t)i * sg.D;
                 const float w0 = w[i];
                 acc0.x += w0 * r[0];
@@ -166,8 +195,8 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
         if (c < sg.D) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) s += red[r * kChunk + tid];
-            a.ctx[(int64_t)b * a.ld_c + sg.ctx_off + c] = s;
+            for (int r = 0; r < kGroups; ++r) s += red[r * kChunk + tid];
+            a.ctx[(int64_t)b * a.ld_c + sg.ctx_off + c] = s * inv;
         }
     }
 }
@@ -312,14 +341,17 @@ int attn_softmax_context_fwd(const mmqg_attn_values& v, const float* scores, int
     MMQG_REQUIRE(ld_s >= S && ld_a >= S && ld_c >= v.H + v.Da + v.Dv, "attn_softmax_context_fwd: leading dimension too small");
     AttnFwdK k;
     k.v = v; k.scores = scores; k.ld_s = ld_s; k.attn = attn; k.ld_a = ld_a; k.ctx = ctx; k.ld_c = ld_c;
-    k.chunks_text = ceil_div(v.H, kChunk);
-    k.chunks_audio = ceil_div(v.Da, kChunk);
-    const int chunks_video = ceil_div(v.Dv, kChunk);
+    static const int chunk = [] { const char* e = getenv("MMQG_ATTN_CHUNK"); return e ? atoi(e) : 64; }();
+    k.chunks_text = ceil_div(v.H, chunk);
+    k.chunks_audio = ceil_div(v.Da, chunk);
+    const int chunks_video = ceil_div(v.Dv, chunk);
     k.vec_text = vec_ok(v.text, v.text_stride_b, v.H);
     k.vec_audio = vec_ok(v.audio, v.audio_stride_b, v.Da);
     k.vec_video = vec_ok(v.video, v.video_stride_b, v.Dv);
     dim3 grid(k.chunks_text + k.chunks_audio + chunks_video, v.B);
-    hipLaunchKernelGGL(attn_softmax_context_fwd_kernel, grid, dim3(256), 0, s, k);
+    if (chunk == 64) hipLaunchKernelGGL(attn_softmax_context_fwd_kernel<64>, grid, dim3(256), 0, s, k);
+    else if (chunk == 256) hipLaunchKernelGGL(attn_softmax_context_fwd_kernel<256>, grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL(attn_softmax_context_fwd_kernel<128>, grid, dim3(256), 0, s, k);
     return check_launch("attn_softmax_context_fwd");
 }
 

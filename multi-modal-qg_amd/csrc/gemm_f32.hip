@@ -281,14 +281,25 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
     a.vec_a = can_vec(A, lda); a.vec_b = can_vec(B, ldb);
     a.vec_a2 = can_vec(A2, lda2); a.vec_b2 = can_vec(B2, ldb2);
 
-    const bool small = (M <= 64) || (N <= 64) || ((int64_t)ceil_div(M, 128) * ceil_div(N, 128) < 96);
-    const int bk = small ? 32 : 16;
+    // Tile shape and K split.  The 128x128 tile reuses each operand byte 4x more than the 64x64 one,
+    // so it is preferred whenever both extents reach 128; K is then split (f32 atomics) until the grid
+    // has at least ~2 workgroups per CU, keeping >= 8 k-tiles per slice.  MMQG_GEMM_HEUR=1 restores the
+    // round-1 rule (big tile only for >= 96 tiles, split-K only on the small tile).
+    static const int heur = env_int("MMQG_GEMM_HEUR", 2);
+    static const int big_bk = env_int("MMQG_GEMM_BIG_BK", 32);
+    const int64_t big_tiles = (int64_t)ceil_div(M, 128) * ceil_div(N, 128);
+    bool small;
+    if (heur == 1) small = (M <= 64) || (N <= 64) || big_tiles < 96;
+    else small = (M <= 64) || (N <= 64) || (M < 128 && N < 256) || (N < 128 && M < 256);
+    const int bk = small ? 32 : big_bk;
     const int nk = ceil_div(K, bk) + (A2 ? ceil_div(K2, bk) : 0);
-    if (split_k < 0) {   // automatic: aim for ~512 workgroups, at least 4 k-tiles per slice
+    if (split_k < 0) {
         split_k = 1;
-        if (small) {
+        if (small) {      // aim for ~384 workgroups, at least 4 k-tiles per slice
             const int64_t tiles = (int64_t)ceil_div(M, 64) * ceil_div(N, 64);
             while (tiles * split_k < 384 && nk / (split_k * 2) >= 4 && split_k < 16) split_k *= 2;
+        } else if (heur != 1) {
+            while (big_tiles * split_k < 448 && nk / (split_k * 2) >= 8 && split_k < 16) split_k *= 2;
         }
     }
     static const int max_split = env_int("MMQG_MAX_SPLITK", 16);      // diagnostics: 1 disables split-K
@@ -310,6 +321,7 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
         }
     }
     if (small) return launch<64, 64, 32>(a, a_layout, b_layout, s);
+    if (big_bk == 32) return launch<128, 128, 32>(a, a_layout, b_layout, s);
     return launch<128, 128, 16>(a, a_layout, b_layout, s);
 }
 
