@@ -235,6 +235,39 @@ typedef struct {
                                                        weight and bias gradients */
 } mmqg_decoder_seq_grad;
 
+/* mmqg_decoder_decode: the free-running decode loop of validate() / evaluate()
+ * (train.py:100-110, evaluate.py:70-103): every step feeds the token picked at the previous step
+ * back through the embedding — all on the device, no host round trip per token.
+ * strategy 0 = greedy argmax (train.py:107-108; evaluate.py 'greedy' and 'topk' with k=1),
+ * strategy 1 = sampling from softmax(logits) (evaluate.py 'sampling'; Gumbel-max with the Philox
+ * stream, so the draw differs from numpy's but has the same distribution).
+ * Stopping at <end> (evaluate.py:101-103) is left to the caller: all T steps are produced. */
+typedef struct {
+    int32_t T, B, L, H, E, V;
+    mmqg_attn_values values;
+    const float* emb_table;                         /* [V][E] */
+    const float* w_attn; const float* b_attn;       /* [Lt+2Lav][E+H] stacked text|audio|video */
+    const float* w_ih[MMQG_MAX_LAYERS]; const float* w_hh[MMQG_MAX_LAYERS];
+    const float* b_ih[MMQG_MAX_LAYERS]; const float* b_hh[MMQG_MAX_LAYERS];
+    const float* w_out; const float* b_out;         /* [V][H], [V] */
+    const float* h0; const float* c0;               /* [L][B][H] */
+    int64_t start_id;
+    int32_t strategy; uint64_t seed;
+    const int64_t* target; const float* row_weight; /* optional [T][B]: per-step loss like validate() */
+    int64_t* ids;                                   /* [T+1][B]: row 0 = start tokens, row t+1 = pick of step t */
+    float* loss_rows;                               /* [T][B] or NULL */
+    float* attn; int32_t ld_attn;                   /* [T][B][ld_attn] attention weights (returned) */
+    float* xemb; float* scores; float* ctx;         /* scratch [B][E], [B][ld_attn], [B][H+Da+Dv] */
+    float* gates;                                   /* scratch [L][B][4H] */
+    float* hs; float* cs;                           /* scratch [2][L][B][H]; final state in slot T%2 */
+    float* logits;                                  /* [T][B][V] if keep_logits else scratch [B][V] */
+    int32_t keep_logits;
+} mmqg_decoder_decode;
+
+int mmqg_decoder_decode_run(const mmqg_decoder_decode* d, mmqg_stream stream);
+int mmqg_sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t seed, uint64_t stream_id,
+                       int64_t* out_ids, mmqg_stream stream);
+
 int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream);
 int mmqg_decoder_seq_bwd(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g, mmqg_stream stream);
 

@@ -70,6 +70,19 @@ class DecoderSeq(C.Structure):
                 ("ctx", c_f), ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f), ("phase", C.c_int32)]
 
 
+class DecoderDecode(C.Structure):
+    _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("E", C.c_int32), ("V", C.c_int32),
+                ("values", AttnValues),
+                ("emb_table", c_f), ("w_attn", c_f), ("b_attn", c_f),
+                ("w_ih", _PTRS), ("w_hh", _PTRS), ("b_ih", _PTRS), ("b_hh", _PTRS),
+                ("w_out", c_f), ("b_out", c_f), ("h0", c_f), ("c0", c_f),
+                ("start_id", c_i64), ("strategy", C.c_int32), ("seed", c_u64),
+                ("target", c_f), ("row_weight", c_f),
+                ("ids", c_f), ("loss_rows", c_f), ("attn", c_f), ("ld_attn", C.c_int32),
+                ("xemb", c_f), ("scores", c_f), ("ctx", c_f), ("gates", c_f), ("hs", c_f), ("cs", c_f),
+                ("logits", c_f), ("keep_logits", C.c_int32)]
+
+
 class DecoderSeqGrad(C.Structure):
     _fields_ = [("dhtop", c_f), ("dgates", c_f), ("dscores", c_f), ("ld_ds", C.c_int32),
                 ("dctx", c_f), ("dh", c_f), ("dc", c_f), ("dxa", c_f), ("dxemb", c_f),
@@ -104,6 +117,8 @@ SIGNATURES = {
     "mmqg_transpose_f32": [c_f, c_i, c_i, c_i, c_f, c_i, c_f],
     "mmqg_lstm_seq_fwd": [C.POINTER(LstmSeq), c_f],
     "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
+    "mmqg_decoder_decode_run": [C.POINTER(DecoderDecode), c_f],
+    "mmqg_sample_gumbel": [c_f, c_i, c_i, c_i, c_u64, c_u64, c_f, c_f],
     "mmqg_decoder_seq_fwd": [C.POINTER(DecoderSeq), c_f],
     "mmqg_decoder_seq_bwd": [C.POINTER(DecoderSeq), C.POINTER(DecoderSeqGrad), c_f],
 }

@@ -22,6 +22,7 @@ int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s);
 int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s);
 int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s);
 int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, hipStream_t s);
+int decoder_decode(const mmqg_decoder_decode& d, hipStream_t s);
 
 }  // namespace mmqg
 
@@ -120,6 +121,14 @@ int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_
 int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream) {
     MMQG_REQUIRE(d, "mmqg_decoder_seq_fwd: null descriptor");
     return decoder_seq_fwd(*d, S(stream));
+}
+int mmqg_decoder_decode_run(const mmqg_decoder_decode* d, mmqg_stream stream) {
+    MMQG_REQUIRE(d, "mmqg_decoder_decode_run: null descriptor");
+    return decoder_decode(*d, S(stream));
+}
+int mmqg_sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t seed, uint64_t stream_id, int64_t* out_ids,
+                       mmqg_stream stream) {
+    return sample_gumbel(logits, ld, rows, V, seed, stream_id, out_ids, S(stream));
 }
 int mmqg_decoder_seq_bwd(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g, mmqg_stream stream) {
     MMQG_REQUIRE(d && g, "mmqg_decoder_seq_bwd: null descriptor");

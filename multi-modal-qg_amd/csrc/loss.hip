@@ -66,6 +66,39 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
     }
 }
 
+// Gumbel-max sampling: argmax_c (logits[c] - log(-log(u_c))) is a draw from softmax(logits)
+__global__ __launch_bounds__(256) void sample_gumbel_kernel(const float* __restrict__ logits, int ld, int V,
+                                                            uint64_t seed, uint64_t stream_id,
+                                                            int64_t* __restrict__ out_ids) {
+    __shared__ float shv[4];
+    __shared__ int shi[4];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = logits + (int64_t)r * ld;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+        uint32_t rnd[4];
+        const uint64_t idx = (uint64_t)r * (uint64_t)V + c;
+        philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream_id,
+                      (uint32_t)(stream_id >> 32), rnd);
+        const float u = ((float)(rnd[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);     // (0,1)
+        const float x = row[c] - logf(-logf(u));
+        if (x > best || (x == best && c < bi)) { best = x; bi = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { shv[wave] = best; shi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (shv[w] > best || (shv[w] == best && shi[w] < bi)) { best = shv[w]; bi = shi[w]; }
+        out_ids[r] = bi;
+    }
+}
+
 // out[n] += sum_m X[m][n]; rows split over blockIdx.y, finished with f32 atomics
 __global__ __launch_bounds__(256) void colsum_add_kernel(const float* __restrict__ X, int ld, int M, int N,
                                                          float* __restrict__ out, int rows_per_block) {
@@ -99,6 +132,11 @@ __global__ __launch_bounds__(256) void fill_copy_kernel(float* __restrict__ dst,
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src ? src[i] : 0.f;
 }
 
+__global__ __launch_bounds__(256) void fill_i64_kernel(int64_t* __restrict__ dst, int64_t value, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
 __global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, int64_t dst_stride,
                                                        const float* __restrict__ src, int64_t src_stride, int rows,
                                                        int cols) {
@@ -122,6 +160,14 @@ int ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* 
     hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, s, logits, ld, target, row_weight, V, loss_rows,
                        argmax, dlogits, ld_d);
     return check_launch("ce_fwd_bwd");
+}
+
+int sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t seed, uint64_t stream_id, int64_t* out_ids,
+                  hipStream_t s) {
+    MMQG_REQUIRE(rows >= 0 && V > 0 && ld >= V && logits && out_ids, "sample_gumbel: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(sample_gumbel_kernel, dim3(rows), dim3(256), 0, s, logits, ld, V, seed, stream_id, out_ids);
+    return check_launch("sample_gumbel");
 }
 
 int colsum_add(const float* X, int ld, int M, int N, float* out, hipStream_t s) {
@@ -157,6 +203,13 @@ int copy_or_zero_f32(float* dst, const float* src, int64_t n, hipStream_t s) {
     const int64_t blocks = std::min<int64_t>(ceil_div64(n, 256), 2048);
     hipLaunchKernelGGL(fill_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, n);
     return check_launch("copy_or_zero_f32");
+}
+
+int fill_i64(int64_t* dst, int64_t value, int64_t n, hipStream_t s) {
+    MMQG_REQUIRE(n >= 0 && dst, "fill_i64: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, dst, value, n);
+    return check_launch("fill_i64");
 }
 
 int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int rows, int cols,

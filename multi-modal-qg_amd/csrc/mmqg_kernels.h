@@ -87,6 +87,9 @@ int embedding_bwd(const float* dout, int ld, const int64_t* ids, float* dtable, 
 int ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* row_weight, int rows, int V,
                float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, hipStream_t s);
 int colsum_add(const float* X, int ld, int M, int N, float* out, hipStream_t s);
+int sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t seed, uint64_t stream_id, int64_t* out_ids,
+                  hipStream_t s);
+int fill_i64(int64_t* dst, int64_t value, int64_t n, hipStream_t s);
 int reduce_sum(const float* x, int n, float* out, hipStream_t s);
 int copy_or_zero_f32(float* dst, const float* src, int64_t n, hipStream_t s);
 int axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s);

@@ -559,3 +559,83 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
 }
 
 }  // namespace mmqg
+
+// ------------------------------------------------------------------------- free-running decode
+namespace mmqg {
+
+// C = (beta?C:0) + bias1 + bias2 + sum of pairs; the fused skinny kernel when the operands allow it,
+// the tiled GEMM otherwise
+static int pairs_product(int M, int N, const SkinnyPair* pr, int np, const float* bias1, const float* bias2, int beta,
+                         float* C, int ldc, hipStream_t s) {
+    if (!g_no_fuse() && !bias2 && skinny_usable(pr, np)) return skinny_plain(M, N, pr, np, bias1, beta, C, ldc, s);
+    for (int i = 0; i < np; ++i)
+        MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, M, N, pr[i].K, pr[i].A, pr[i].lda, pr[i].B, pr[i].ldb, nullptr, 0,
+                          nullptr, 0, 0, i == 0 ? bias1 : nullptr, i == 0 ? bias2 : nullptr, i == 0 ? beta : 1, C, ldc, 1, s));
+    return 0;
+}
+
+int decoder_decode(const mmqg_decoder_decode& d, hipStream_t s) {
+    MMQG_REQUIRE(d.T >= 0 && d.B >= 0 && d.H > 0 && d.E > 0 && d.V > 0, "decoder_decode: bad shape");
+    MMQG_REQUIRE(d.L >= 1 && d.L <= MMQG_MAX_LAYERS, "decoder_decode: L must be in [1,%d]", MMQG_MAX_LAYERS);
+    MMQG_REQUIRE(d.values.B == d.B, "decoder_decode: values.B must equal B");
+    MMQG_REQUIRE(d.emb_table && d.w_attn && d.b_attn && d.w_out && d.b_out && d.h0 && d.c0, "decoder_decode: null input");
+    MMQG_REQUIRE(d.ids && d.attn && d.xemb && d.scores && d.ctx && d.gates && d.hs && d.cs && d.logits,
+                 "decoder_decode: null buffer");
+    MMQG_REQUIRE(d.strategy == 0 || d.strategy == 1, "decoder_decode: strategy must be 0 (greedy) or 1 (sampling)");
+    MMQG_REQUIRE(!d.loss_rows || d.target, "decoder_decode: loss requested without targets");
+    for (int l = 0; l < d.L; ++l)
+        MMQG_REQUIRE(d.w_ih[l] && d.w_hh[l] && d.b_ih[l] && d.b_hh[l], "decoder_decode: null weight (layer %d)", l);
+    if (d.B == 0) return 0;
+    const int T = d.T, B = d.B, H = d.H, L = d.L, E = d.E, V = d.V;
+    const mmqg_attn_values& v = d.values;
+    const int S = v.Lt + 2 * v.Lav, C = v.H + v.Da + v.Dv, Q = E + H, In0 = E + C, ldS = d.ld_attn;
+    MMQG_REQUIRE(ldS >= S, "decoder_decode: ld_attn too small");
+    const int64_t BH = (int64_t)B * H, LBH = (int64_t)L * BH, G = (int64_t)B * 4 * H;
+    MMQG_TRY(copy_or_zero(d.hs, d.h0, (size_t)LBH, s));
+    MMQG_TRY(copy_or_zero(d.cs, d.c0, (size_t)LBH, s));
+    MMQG_TRY(fill_i64(d.ids, d.start_id, B, s));
+    for (int t = 0; t < T; ++t) {
+        const float* h_in = d.hs + (t & 1) * LBH;
+        const float* c_in = d.cs + (t & 1) * LBH;
+        float* h_out = d.hs + ((t + 1) & 1) * LBH;
+        float* c_out = d.cs + ((t + 1) & 1) * LBH;
+        float* at = d.attn + (int64_t)t * B * ldS;
+        MMQG_TRY(embedding_fwd(d.emb_table, d.ids + (int64_t)t * B, d.xemb, B, V, E, E, s));            // decoder.py:75
+        // scores = [emb | h_top] * W_attn^T + b                                                         decoder.py:78,84,92
+        SkinnyPair sp[2] = {{d.xemb, E, d.w_attn, Q, E, 0}, {h_in + (int64_t)(L - 1) * BH, H, d.w_attn + E, Q, H, 0}};
+        MMQG_TRY(pairs_product(B, S, sp, 2, d.b_attn, nullptr, 0, d.scores, ldS, s));
+        MMQG_TRY(attn_softmax_context_fwd(v, d.scores, ldS, at, ldS, d.ctx, C, s));
+        for (int l = 0; l < L; ++l) {
+            float* gates = d.gates + (int64_t)l * G;
+            SkinnyPair pr[3];
+            int np = 0;
+            if (l == 0) {
+                pr[np++] = SkinnyPair{d.xemb, E, d.w_ih[0], In0, E, 0};
+                pr[np++] = SkinnyPair{d.ctx, C, d.w_ih[0] + E, In0, C, 0};
+            } else {
+                pr[np++] = SkinnyPair{h_out + (int64_t)(l - 1) * BH, H, d.w_ih[l], H, H, 0};
+            }
+            pr[np++] = SkinnyPair{h_in + l * BH, H, d.w_hh[l], H, H, 0};
+            CellFwd c{};
+            c.B = B; c.H = H; c.gates = gates; c.ld_g = 4 * H;
+            c.h_prev = h_in + l * BH; c.c_prev = c_in + l * BH; c.h_out = h_out + l * BH; c.c_out = c_out + l * BH;
+            if (!g_no_fuse() && H % 4 == 0 && skinny_usable(pr, np)) {
+                MMQG_TRY(skinny_cell_fwd(pr, np, 0, d.b_ih[l], d.b_hh[l], c, s));
+            } else {
+                MMQG_TRY(pairs_product(B, 4 * H, pr, np, d.b_ih[l], d.b_hh[l], 0, gates, 4 * H, s));
+                MMQG_TRY(lstm_cell_fwd(c, s));
+            }
+        }
+        float* logits = d.keep_logits ? d.logits + (int64_t)t * B * V : d.logits;
+        const SkinnyPair op{h_out + (int64_t)(L - 1) * BH, H, d.w_out, H, H, 0};
+        MMQG_TRY(pairs_product(B, V, &op, 1, d.b_out, nullptr, 0, logits, V, s));                        // decoder.py:106
+        int64_t* next = d.ids + (int64_t)(t + 1) * B;
+        MMQG_TRY(ce_fwd_bwd(logits, V, d.target ? d.target + (int64_t)t * B : nullptr,
+                            d.row_weight ? d.row_weight + (int64_t)t * B : nullptr, B, V,
+                            d.loss_rows ? d.loss_rows + (int64_t)t * B : nullptr, next, nullptr, 0, s));
+        if (d.strategy == 1) MMQG_TRY(sample_gumbel(logits, V, B, V, d.seed, (uint64_t)t, next, s));
+    }
+    return 0;
+}
+
+}  // namespace mmqg

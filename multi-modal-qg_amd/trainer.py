@@ -484,6 +484,71 @@ class BatchedTrainer:
 
     # ------------------------------------------------------------------------- inference
     @torch.no_grad()
+    def decode(self, batch: dict, max_len: Optional[int] = None, strategy: str = "greedy", seed: int = 0,
+               with_loss: bool = False, keep_logits: bool = False):
+        """Free-running decode of validate() / evaluate() (train.py:87-110, evaluate.py:52-103) for a
+        batch, eval mode: encoders once, then ``max_len`` decoder steps that feed each picked token
+        back in, all on the device.  strategy: 'greedy' (== 'topk' with k=1) or 'sampling'.
+        Returns dict(ids (B,max_len) int64, attn (max_len,B,S), loss (scalar tensor, validate()'s
+        per-step CE against ``batch['target']`` averaged like the training loss) or None,
+        logits (max_len,B,V) or None).  Tokens after <end> are still produced; use
+        ``truncate_at_end`` for evaluate.py's stopping rule."""
+        T = max_len or self.Td
+        raw = self.load_batch(batch)
+        if raw is not None:
+            was = self.video.training
+            self.video.eval()
+            self.ws["feats"].copy_(self.video.cnn_features(raw, self.ws["n_frames"]).transpose(0, 1))
+            self.video.train(was)
+        lib, w = _lib.load(), self.ws
+        L, B, H, V, E = self.L, self.B, self.H, self.V, self.E
+        s = ops._stream()
+        for d in (self.d_vid, self.d_text):
+            d.training = 0
+        self.d_text.dropout_p = 0.0
+        emb = self.dec.emb_layer.weight
+        check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_vid), s), "lstm_seq_fwd(frames)")
+        ops.embedding_fwd(emb, w["ids_c"], w["xemb_c"].view(-1, E))
+        check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_text), s), "lstm_seq_fwd(text)")
+        w["h0_d"].copy_(w["hs_t"][:, self.Tc])
+        w["c0_d"].copy_(w["cs_t"][:, self.Tc])
+        dev = self.dev
+        ids = torch.zeros(T + 1, B, device=dev, dtype=torch.int64)
+        attn = torch.zeros(T, B, self.ldS, device=dev)
+        logits = torch.empty((T if keep_logits else 1), B, V, device=dev)
+        hs, cs = torch.empty(2, L, B, H, device=dev), torch.empty(2, L, B, H, device=dev)
+        xemb, scores, ctx = torch.empty(B, E, device=dev), torch.zeros(B, self.ldS, device=dev), torch.empty(B, self.Cw, device=dev)
+        gates = torch.empty(L, B, 4 * H, device=dev)
+        loss_rows = target = row_w = None
+        if with_loss:
+            if T > self.Td:
+                raise ValueError("with_loss needs max_len <= the target length the trainer was built for")
+            loss_rows = torch.zeros(T, B, device=dev)
+            target, row_w = w["target"], w["row_w"]
+        d = _lib.DecoderDecode()
+        d.T, d.B, d.L, d.H, d.E, d.V = T, B, L, H, E, V
+        d.values = self.d_dec.values
+        d.emb_table = emb.data_ptr()
+        d.w_attn, d.b_attn = self.d_dec.w_attn, self.d_dec.b_attn
+        for l in range(L):
+            d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (self.d_dec.w_ih[l], self.d_dec.w_hh[l], self.d_dec.b_ih[l],
+                                                          self.d_dec.b_hh[l])
+        d.w_out, d.b_out = self.dec.out_layer.weight.data_ptr(), self.dec.out_layer.bias.data_ptr()
+        d.h0, d.c0 = w["h0_d"].data_ptr(), w["c0_d"].data_ptr()
+        d.start_id = self.start_id
+        d.strategy = {"greedy": 0, "topk": 0, "sampling": 1}[strategy]
+        d.seed = seed
+        d.target, d.row_weight = ptr(target), ptr(row_w)
+        d.ids, d.loss_rows = ids.data_ptr(), ptr(loss_rows)
+        d.attn, d.ld_attn = attn.data_ptr(), self.ldS
+        d.xemb, d.scores, d.ctx, d.gates = xemb.data_ptr(), scores.data_ptr(), ctx.data_ptr(), gates.data_ptr()
+        d.hs, d.cs, d.logits, d.keep_logits = hs.data_ptr(), cs.data_ptr(), logits.data_ptr(), int(keep_logits)
+        check(lib.mmqg_decoder_decode_run(C.byref(d), s), "decoder_decode_run")
+        return dict(ids=ids[1:].t().contiguous(), attn=attn[:, :, :self.S],
+                    loss=loss_rows.sum() if with_loss else None, logits=logits if keep_logits else None,
+                    hidden=(hs[T % 2], cs[T % 2]))
+
+    @torch.no_grad()
     def logits(self) -> torch.Tensor:
         """(B,Td,V) logits of the last forward (before the loss kernel overwrote them with
         their gradient they are only valid after ``forward_only``)."""

@@ -374,3 +374,37 @@ def test_two_rank_data_parallel_step_equals_single_rank_full_batch(mm, use_graph
     for _ in range(2):
         tr.step(full)
     close(res[0], tr.flat_p, tol=2e-6, what="2-rank DP weights vs single-rank full batch")
+
+
+# ------------------------------------------------------------ free-running decode (validate / evaluate)
+def test_device_decode_matches_reference_greedy_ids_and_validate_loss(mm):
+    from mmqg_amd.metrics import truncate_at_end
+    z = load_npz("small_model.npz")
+    samples = small_samples(z)
+    c, cfg, vid, text, dec = build_small(mm, z, prefix="adam/1")
+    batch = collate(samples)
+    tr = _trainer(mm, vid, text, dec, batch).eval()
+    out = tr.decode(batch, with_loss=True, keep_logits=True)
+    for b in range(3):
+        n = int(batch["tgt_len"][b])
+        assert out["ids"][b, :n].tolist() == z[f"eval/{b}/ids"].tolist()           # train.py:100-110, bit-exact
+        close(out["logits"][:n, b], z[f"eval/{b}/logits"], what=f"decode logits q{b}")
+    want = np.mean([float(z[f"eval/{b}/loss"]) for b in range(3)])                   # (1/B) sum_b validate-loss_b
+    close(out["loss"].view(()), np.float32(want), what="validate loss")
+    long = tr.decode(batch, max_len=8)                                               # evaluate.py: stop at <end>
+    for b in range(3):
+        assert truncate_at_end(long["ids"][b].tolist(), c["end_id"])[:8] == [t for t in z[f"eval/{b}/ids_stop"].tolist() if t != c["end_id"]]
+
+
+def test_device_sampling_follows_the_softmax_distribution(mm):
+    from mmqg_amd import _lib, ops
+    V, rows = 7, 4096
+    logits = torch.tensor([2.0, 0.0, 1.0, -1.0, 0.5, -3.0, 1.5]).repeat(rows, 1).cuda()
+    ids = torch.empty(rows, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.load().mmqg_sample_gumbel(logits.data_ptr(), V, rows, V, 123, 0, ids.data_ptr(), ops._stream()))
+    freq = torch.bincount(ids.cpu(), minlength=V).double() / rows
+    p = torch.softmax(logits[0].double().cpu(), 0)
+    assert float((freq - p).abs().max()) < 4 * float((p * (1 - p) / rows).sqrt().max()) + 0.005
+    ids2 = torch.empty_like(ids)
+    _lib.check(_lib.load().mmqg_sample_gumbel(logits.data_ptr(), V, rows, V, 123, 0, ids2.data_ptr(), ops._stream()))
+    assert torch.equal(ids, ids2)

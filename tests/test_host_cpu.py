@@ -38,10 +38,13 @@ def test_ctypes_structs_match_the_c_layout(lib_mod, tmp_path):
     """Compile a tiny C program against include/mmqg.h that prints sizeof/offsetof and compare
     with the ctypes mirror."""
     fields = {"mmqg_attn_values": ("AttnValues", ["B", "text", "video_stride_b", "mask_mode"]),
-              "mmqg_lstm_seq": ("LstmSeq", ["x", "w_hh", "lens", "seed", "seed_offset", "gates", "y_stride_b"]),
-              "mmqg_lstm_seq_grad": ("LstmSeqGrad", ["dy", "dgates", "lddx", "db_hh", "dc0"]),
-              "mmqg_decoder_seq": ("DecoderSeq", ["values", "xemb", "b_hh", "seed_offset", "scores", "ld_attn", "hdrop"]),
-              "mmqg_decoder_seq_grad": ("DecoderSeqGrad", ["dhtop", "ld_ds", "dxemb", "db_hh", "n_text_rows", "dvideo_stride_b"])}
+              "mmqg_lstm_seq": ("LstmSeq", ["x", "w_hh", "w_hhT", "w_ihT", "lens", "seed", "seed_offset", "gates", "y_stride_b"]),
+              "mmqg_lstm_seq_grad": ("LstmSeqGrad", ["dy", "dgates", "lddx", "db_hh", "dc0", "phase"]),
+              "mmqg_decoder_seq": ("DecoderSeq", ["values", "xemb", "b_hh", "w_ihT", "w_attn_hT", "seed_offset", "scores",
+                                                  "ld_attn", "hdrop", "phase"]),
+              "mmqg_decoder_seq_grad": ("DecoderSeqGrad", ["dhtop", "ld_ds", "dxemb", "db_hh", "n_text_rows", "dvideo_stride_b", "phase"]),
+              "mmqg_decoder_decode": ("DecoderDecode", ["values", "emb_table", "b_hh", "w_out", "start_id", "seed", "target",
+                                                        "ids", "ld_attn", "xemb", "hs", "logits", "keep_logits"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mmqg.h"', 'int main(void){']
     for cname, (_, fs) in fields.items():
         src.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -148,3 +151,17 @@ def test_synthetic_batches_are_seeded_and_reserve_special_ids():
         assert (a["frames"][i, int(a["n_frames"][i]):] == 0).all()
     assert WORKLOADS["config2"].batch == 64 and WORKLOADS["config2"].text_max_length == 283
     assert WORKLOADS["config5"].vocab == 50000 and WORKLOADS["config5"].hidden == 1024
+
+
+def test_bleu_restatement_known_values():
+    from mmqg_amd.metrics import reference_bleu_scores, sentence_bleu, truncate_at_end
+    ref = "the cat is on the mat".split()
+    assert sentence_bleu([ref], ref) == pytest.approx(1.0)
+    assert sentence_bleu([ref], "the cat".split(), (1, 0, 0, 0)) == pytest.approx(2.718281828 ** (1 - 6 / 2))   # brevity penalty only
+    hyp = "the the the the the the the".split()
+    assert sentence_bleu([ref], hyp, (1, 0, 0, 0)) == pytest.approx(2 / 7)           # clipped unigram precision
+    assert sentence_bleu([ref], "dog".split()) == 0.0
+    # the reference's call: every reference is ONE WORD iterated as characters (train.py:115)
+    s = reference_bleu_scores("what is a", ["a", "b"])
+    assert s["bleu_1"] == pytest.approx(0.5) and 0.0 < s["bleu"] < 1e-50
+    assert truncate_at_end([5, 7, 2, 9], 2) == [5, 7]
