@@ -266,6 +266,13 @@ class BatchedTrainer:
         dd.w_ih0cT, dd.w_attn_hT = w["wih0cT"].data_ptr(), w["wattn_hT"].data_ptr()
         self.d_dec, self.g_dec = dd, gd
 
+    def set_seed(self, seed: int) -> None:
+        """Seed of the dropout streams (mixed with the device-side step counter at run time)."""
+        self.seed = int(seed)
+        for d in (self.d_vid, self.d_text, self.d_dec):
+            d.seed = self.seed
+        self._graph = None            # kernel arguments are frozen into captured graphs
+
     # ------------------------------------------------------------------------------ modes
     def train(self, mode: bool = True):
         self.training = mode

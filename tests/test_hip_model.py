@@ -408,3 +408,31 @@ def test_device_sampling_follows_the_softmax_distribution(mm):
     ids2 = torch.empty_like(ids)
     _lib.check(_lib.load().mmqg_sample_gumbel(logits.data_ptr(), V, rows, V, 123, 0, ids2.data_ptr(), ops._stream()))
     assert torch.equal(ids, ids2)
+
+
+def test_training_state_resume_reproduces_the_run(mm, tmp_path):
+    """Optimizer state + step counter + dropout seed survive save/load (the reference saves weights
+    only, train.py:198-214): two more steps after a resume equal two more steps without one."""
+    from mmqg_amd.checkpoint import load_training_state, save_training_state
+    from mmqg_amd.synthetic import build_models
+    w, batch = _oracle_setup(4, 5, 0.2, True)
+    vid, text, dec = build_models(w, "cuda", seed=4)
+    tr = _trainer(mm, vid, text, dec, batch, seed=11).train()
+    for _ in range(2):
+        tr.step(batch)
+    save_training_state(tmp_path / "state.pt", tr, epoch=3)
+    ref = [float(tr.step(batch)) for _ in range(2)]
+    ref_p = tr.flat_p.clone()
+    vid2, text2, dec2 = build_models(w, "cuda", seed=99)          # different weights: must be overwritten
+    tr2 = _trainer(mm, vid2, text2, dec2, batch, seed=0).train()
+    st = load_training_state(tmp_path / "state.pt", tr2)
+    assert st["epoch"] == 3 and int(tr2.step_dev) == 2
+    got = [float(tr2.step(batch)) for _ in range(2)]
+    assert got == pytest.approx(ref, rel=1e-6)
+    close(tr2.flat_p, ref_p, tol=1e-6, what="weights after resume")
+    assert torch.equal(dec2.out_layer.weight, tr2.flat_p[slice(*_param_range(tr2, dec2.out_layer.weight))].view_as(dec2.out_layer.weight))
+
+
+def _param_range(tr, p):
+    off = (p.data_ptr() - tr.flat_p.data_ptr()) // 4
+    return off, off + p.numel()
