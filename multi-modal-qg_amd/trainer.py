@@ -80,8 +80,11 @@ class BatchedTrainer:
         self._flatten_parameters()
         self._allocate()
         self._describe()
-        self.use_graph = use_graph
+        # hipGraph replay only on a single GPU: eager launches are as fast here (the step is bound by
+        # the GPU-side dependency chain, not by the host) and keep RCCL entirely outside stream capture
+        self.use_graph = use_graph and self.world == 1
         self._graph = None
+        self._dec_reduced = False
         self._side = torch.cuda.Stream(device=self.dev)
         self.reducer = GradReducer(self.flat_g, trainer_buckets(self.segments, self.n_params), self.pg)
         if self.world > 1:
@@ -383,6 +386,11 @@ class BatchedTrainer:
             self.g_dec.phase = 2
             check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s2), "decoder_seq_bwd(wgrad)")
             ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
+            if self.world > 1 and not torch.cuda.is_current_stream_capturing():
+                # the decoder bucket (everything but the embedding) is final here: start its all-reduce
+                # from the side stream so it runs beside the text encoder's backward
+                self.reducer.reduce("dec")
+                self._dec_reduced = True
             self.g_vid.phase = 0
             check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s2), "lstm_seq_bwd(frames)")
         self.g_dec.phase = 0
@@ -431,9 +439,11 @@ class BatchedTrainer:
 
     def _allreduce(self):
         if self.world > 1:
-            self.reducer.reduce("dec")
+            if not self._dec_reduced:
+                self.reducer.reduce("dec")
             self.reducer.reduce("rest")
             self.reducer.finish()
+            self._dec_reduced = False
 
     def forward_backward(self, batch: Optional[dict] = None):
         """zero_grad + forward + loss + backward for the batch already loaded (or ``batch``).
@@ -480,9 +490,9 @@ class BatchedTrainer:
             # [Adam]; the gradient all-reduce sits between them (RCCL is not captured)
             self._graph = torch.cuda.CUDAGraph()
             self._graph_adam = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 self._graph_body()
-            with torch.cuda.graph(self._graph_adam, pool=self._graph.pool()):
+            with torch.cuda.graph(self._graph_adam, pool=self._graph.pool(), capture_error_mode="thread_local"):
                 self._adam()
         self._graph.replay()
         self._allreduce()

@@ -2,6 +2,8 @@
 its own (train.py:149-181, one question at a time) and the batched trainer, against the golden
 vectors captured from the reference (tests/golden/*.npz) and against the CPU oracle on seeded
 inputs.  fp32 tolerance 1e-4; greedy token ids bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -436,3 +438,53 @@ def test_training_state_resume_reproduces_the_run(mm, tmp_path):
 def _param_range(tr, p):
     off = (p.data_ptr() - tr.flat_p.data_ptr()) // 4
     return off, off + p.numel()
+
+
+def test_train_driver_on_a_tiny_corpus_in_the_reference_formats(mm, tmp_path, capsys):
+    """train_mi355x.py --config: reference on-disk formats -> batched steps -> validate()-style decode +
+    BLEU -> reference checkpoint files."""
+    import json
+    import types
+    import train_mi355x as drv
+    from mmqg_amd.config import Config
+    words = ["<pad>", "<start>", "<end>"] + [f"w{i}" for i in range(17)]
+    vocab = {w: i for i, w in enumerate(words)}
+    rng = np.random.default_rng(0)
+    (tmp_path / "frames").mkdir(); (tmp_path / "audio").mkdir(); (tmp_path / "out").mkdir(); (tmp_path / "data").mkdir()
+    qs = []
+    for i in range(6):
+        T = int(rng.integers(1, 4))
+        q = {"video_id": f"v{i}", "question_id": i, "context": " ".join(rng.choice(words[3:], 5)),
+             "question": " ".join(rng.choice(words[3:], 4))}
+        qs.append(q)
+        stem = f"v_{q['video_id']}_q_{q['question_id']}_"
+        np.save(tmp_path / "frames" / (stem + ".npy"), rng.integers(0, 256, (T, 112, 112, 3), dtype=np.uint8))
+        np.save(tmp_path / "audio" / (stem + ".npy"), rng.standard_normal((T, 128)).astype(np.float32))
+    for name in ("train", "val"):
+        json.dump(qs[:4] if name == "train" else qs[4:], open(tmp_path / "data" / f"{name}_questions.json", "w"))
+    json.dump(vocab, open(tmp_path / "data" / "vocab.json", "w"))
+    json.dump({str(i): w for w, i in vocab.items()}, open(tmp_path / "data" / "index_to_word.json", "w"))
+    np.save(tmp_path / "data" / "weight_matrix.npy", rng.standard_normal((len(words), 300)))
+    saved = {k: getattr(Config, k) for k in Config._public()}
+    try:
+        cfgd = {"output_path": str(tmp_path / "out"), "data_path": str(tmp_path / "data"),
+                "av_model_path": str(tmp_path / "out" / "av_model.pth"), "text_enc_model_path": str(tmp_path / "out" / "text_enc_model.pth"),
+                "dec_model_path": str(tmp_path / "out" / "dec_model.pth"), "learned_weight_path": str(tmp_path / "out" / "learned_weight.pt"),
+                "train_file": str(tmp_path / "data" / "train_questions.json"), "val_file": str(tmp_path / "data" / "val_questions.json"),
+                "vocab_file": str(tmp_path / "data" / "vocab.json"), "index_to_word_file": str(tmp_path / "data" / "index_to_word.json"),
+                "weights_matrix_file": str(tmp_path / "data" / "weight_matrix.npy"),
+                "salient_frames_path": str(tmp_path / "frames"), "salient_audio_path": str(tmp_path / "audio"),
+                "batch_size": 2, "question_max_length": 6}
+        json.dump(cfgd, open(tmp_path / "cfg.json", "w"))
+        a = types.SimpleNamespace(config=str(tmp_path / "cfg.json"), batch=0, epochs=2, seed=0, max_frames=4, max_context=8)
+        drv.run_real(a, 1, 0, torch.device("cuda", 0))
+        out = capsys.readouterr().out.strip().splitlines()
+        stats = [json.loads(l) for l in out if l.startswith("{")]
+        assert len(stats) == 2 and all(np.isfinite(s["train_loss"]) and np.isfinite(s["val_loss"]) for s in stats)
+        assert stats[1]["train_loss"] < stats[0]["train_loss"] + 0.5 and 0.0 <= stats[0]["bleu_1"] <= 1.0
+        have = set(os.listdir(tmp_path / "out"))
+        assert {"av_model.pth", "text_enc_model.pth", "dec_model.pth", "learned_weight.pt", "last_decoder.pth",
+                "training_state.pt", "config.json"} <= have
+    finally:
+        for k, v in saved.items():
+            setattr(Config, k, v)
