@@ -314,9 +314,11 @@ int launch_skinny_batch(const SkinnyBatch& b, int njobs, hipStream_t s, const ch
         chunks = std::max(chunks, k.chunks);
     }
     dim3 grid(tiles_n, tiles_m, njobs);
-    // enough K per wave to amortise the reduction; 8 waves once a tile has >= 64 chunks
+    // 8 k-slices per tile once a tile has >= 64 k-chunks, unless that would put more than ~4096 waves
+    // in flight (three layer-steps in one launch): beyond that the extra waves only add fixed cost
     static const int ks8_from = [] { const char* e = getenv("MMQG_SKINNY_KS8_FROM"); return e ? atoi(e) : 64; }();
-    if (chunks >= ks8_from) hipLaunchKernelGGL((skinny_kernel<MODE, 8>), grid, dim3(512), 0, s, b);
+    const int64_t wgs = (int64_t)tiles_n * tiles_m * njobs;
+    if (chunks >= ks8_from && wgs * 8 <= 4096) hipLaunchKernelGGL((skinny_kernel<MODE, 8>), grid, dim3(512), 0, s, b);
     else hipLaunchKernelGGL((skinny_kernel<MODE, 4>), grid, dim3(256), 0, s, b);
     return mmqg::check_launch(what);
 }
