@@ -423,3 +423,56 @@ def test_transpose(mm):
     _lib.check(_lib.load().mmqg_transpose_f32(s_d.data_ptr(), 136, 77, 130, dst.data_ptr(), 80, ops._stream()))
     assert torch.equal(dst[:, :77].cpu(), src[:, :130].t())
     assert torch.all(dst[:, 77:] == -1.0)
+
+
+# ------------------------------------------------------------------------------ edge cases
+def test_empty_and_degenerate_shapes(mm):
+    _lib, ops = mm
+    lib = _lib.load()
+    x = torch.zeros(4, 4, device="cuda")
+    ops.gemm(0, 0, 0, 4, 4, x, 4, x, 4, x, 4)                     # M = 0: nothing to do
+    ops.gemm(0, 0, 4, 0, 4, x, 4, x, 4, x, 4)                     # N = 0
+    out = ops.embedding_fwd(torch.randn(5, 8, device="cuda"), torch.zeros(0, dtype=torch.int64, device="cuda"))
+    assert out.shape == (0, 8)
+    _lib.check(lib.mmqg_ce_fwd_bwd(x.data_ptr(), 4, None, None, 0, 4, None, None, None, 0, ops._stream()))
+    # single question, single value row per modality
+    g = torch.Generator().manual_seed(0)
+    sc, text, audio, video, tl, al = _attn_case(g, 1, 1, 1, 8, 4, 8)
+    attn, ctx = ops.AttentionFn.apply(sc.cuda(), text.cuda(), audio.cuda(), video.cuda(), None, None, 0)
+    assert torch.allclose(attn.cpu(), torch.ones(1, 3))          # softmax over one slot
+    close(ctx, torch.cat((text[0, 0], audio[0, 0], video[0, 0]))[None], what="single-row context")
+
+
+def test_sequence_with_rows_that_never_start(mm):
+    """lens[b] == 0: the row keeps its initial state through the whole sequence, its outputs are
+    zero rows (what train.py:160's zero-initialised all_enc_outputs holds) and it gets no gradient."""
+    _lib, ops = mm
+    lib = _lib.load()
+    T, B, L, H, In = 4, 3, 2, 16, 8
+    g = torch.Generator().manual_seed(1)
+    params = []
+    for l in range(L):
+        d = In if l == 0 else H
+        params += [torch.randn(4 * H, d, generator=g) * 0.3, torch.randn(4 * H, H, generator=g) * 0.3,
+                   torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1]
+    params = [p.cuda() for p in params]
+    x = torch.randn(T, B, In, generator=g).cuda()
+    h0 = torch.randn(L, B, H, generator=g).cuda()
+    c0 = torch.randn(L, B, H, generator=g).cuda()
+    lens = torch.tensor([0, 4, 2], dtype=torch.int32, device="cuda")
+    d = _lib.LstmSeq()
+    d.T, d.B, d.L, d.H, d.In = T, B, L, H, In
+    d.x, d.ldx = x.data_ptr(), In
+    for l in range(L):
+        d.w_ih[l], d.w_hh[l], d.b_ih[l], d.b_hh[l] = (p.data_ptr() for p in params[4 * l:4 * l + 4])
+    d.h0, d.c0, d.lens = h0.data_ptr(), c0.data_ptr(), lens.data_ptr()
+    gates = torch.empty(L, T, B, 4 * H, device="cuda")
+    hs, cs = torch.empty(L, T + 1, B, H, device="cuda"), torch.empty(L, T + 1, B, H, device="cuda")
+    y = torch.full((T, B, H), 9.0, device="cuda")
+    d.gates, d.hs, d.cs = gates.data_ptr(), hs.data_ptr(), cs.data_ptr()
+    d.y, d.y_stride_t, d.y_stride_b = y.data_ptr(), B * H, H
+    _lib.check(lib.mmqg_lstm_seq_fwd(C.byref(d), ops._stream()))
+    assert torch.equal(hs[:, T, 0], h0[:, 0]) and torch.equal(cs[:, T, 0], c0[:, 0])      # never started: state carried
+    assert float(y[:, 0].abs().sum()) == 0 and float(y[2:, 2].abs().sum()) == 0           # zero rows past the length
+    assert float(y[:2, 2].abs().sum()) > 0 and float(gates[:, :, 0].abs().sum()) == 0
+    assert torch.equal(hs[:, T, 2], hs[:, 2, 2])                                           # row 2 frozen after 2 steps
