@@ -271,6 +271,46 @@ int mmqg_sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t se
 int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream);
 int mmqg_decoder_seq_bwd(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g, mmqg_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Frame CNN of VideoConvLstmEncoder (encoder.py:40-50,64-67): blocks of 3x3 valid convolution
+ * (stride 1) -> ReLU -> BatchNorm2d whose batch is the T frames of ONE question, optional 3x3/3
+ * max-pool.  frames [B][T][Cin][H][W] ([T][B]... with time_major) is the layout after the reference's
+ * view(T,C,H,W);
+ * frames with t >= n_frames[b] are left out of the statistics and give zero features.
+ * Training mode uses per-question batch statistics and advances running_mean/var once per
+ * question in batch order; eval mode normalises with the running statistics. */
+#define MMQG_CNN_MAX_BLOCKS 4
+typedef struct {
+    int32_t cout; int32_t pool;
+    const float* w; const float* bias;              /* [cout][cin][3][3], [cout] */
+    const float* gamma; const float* beta;          /* BatchNorm affine [cout] */
+    float* running_mean; float* running_var;        /* [cout] */
+    float* y;                                       /* [B*T][cout][h-2][w-2] relu(conv), kept for backward */
+    float* z;                                       /* block output [B*T][cout][hz][wz] */
+    uint8_t* argmax;                                /* pooled blocks: [B*T][cout][hz][wz] */
+    double* stats;                                  /* [B][cout][2] scratch */
+    float* mean; float* invstd; float* scale; float* shift;   /* [B][cout] */
+} mmqg_cnn_block;
+
+typedef struct {
+    int32_t B, T, Cin, H, W, n_blocks, training;
+    int32_t time_major;                             /* 0: frames and every block buffer are [B][T]...; 1: [T][B]... */
+    float eps, momentum;
+    const float* frames;
+    const int32_t* n_frames;                        /* [B] or NULL */
+    mmqg_cnn_block block[MMQG_CNN_MAX_BLOCKS];
+} mmqg_frame_cnn;
+
+typedef struct {
+    const float* dfeat;                             /* gradient of the last block's output */
+    float* dconv; float* dz;                        /* scratch: largest y / largest block input */
+    float* dw[MMQG_CNN_MAX_BLOCKS]; float* dbias[MMQG_CNN_MAX_BLOCKS];     /* accumulated (+=) */
+    float* dgamma[MMQG_CNN_MAX_BLOCKS]; float* dbeta[MMQG_CNN_MAX_BLOCKS];
+} mmqg_frame_cnn_grad;
+
+int mmqg_frame_cnn_fwd(const mmqg_frame_cnn* d, mmqg_stream stream);
+int mmqg_frame_cnn_bwd(const mmqg_frame_cnn* d, const mmqg_frame_cnn_grad* g, mmqg_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

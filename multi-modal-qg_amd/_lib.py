@@ -93,6 +93,29 @@ class DecoderSeqGrad(C.Structure):
                 ("phase", C.c_int32)]
 
 
+CNN_MAX_BLOCKS = 4
+
+
+class CnnBlock(C.Structure):
+    _fields_ = [("cout", C.c_int32), ("pool", C.c_int32), ("w", c_f), ("bias", c_f), ("gamma", c_f), ("beta", c_f),
+                ("running_mean", c_f), ("running_var", c_f), ("y", c_f), ("z", c_f), ("argmax", c_f), ("stats", c_f),
+                ("mean", c_f), ("invstd", c_f), ("scale", c_f), ("shift", c_f)]
+
+
+class FrameCnn(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("Cin", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("n_blocks", C.c_int32), ("training", C.c_int32), ("time_major", C.c_int32), ("eps", c_fl), ("momentum", c_fl),
+                ("frames", c_f), ("n_frames", c_f), ("block", CnnBlock * CNN_MAX_BLOCKS)]
+
+
+_CPTRS = c_f * CNN_MAX_BLOCKS
+
+
+class FrameCnnGrad(C.Structure):
+    _fields_ = [("dfeat", c_f), ("dconv", c_f), ("dz", c_f), ("dw", _CPTRS), ("dbias", _CPTRS), ("dgamma", _CPTRS),
+                ("dbeta", _CPTRS)]
+
+
 # name -> argtypes (return type is int unless noted); kept in one table so the CPU test can
 # check that the shared object exports every symbol the header declares.
 SIGNATURES = {
@@ -119,6 +142,8 @@ SIGNATURES = {
     "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
     "mmqg_decoder_decode_run": [C.POINTER(DecoderDecode), c_f],
     "mmqg_sample_gumbel": [c_f, c_i, c_i, c_i, c_u64, c_u64, c_f, c_f],
+    "mmqg_frame_cnn_fwd": [C.POINTER(FrameCnn), c_f],
+    "mmqg_frame_cnn_bwd": [C.POINTER(FrameCnn), C.POINTER(FrameCnnGrad), c_f],
     "mmqg_decoder_seq_fwd": [C.POINTER(DecoderSeq), c_f],
     "mmqg_decoder_seq_bwd": [C.POINTER(DecoderSeq), C.POINTER(DecoderSeqGrad), c_f],
 }

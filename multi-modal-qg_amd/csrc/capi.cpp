@@ -118,6 +118,14 @@ int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_
     MMQG_REQUIRE(d && g, "mmqg_lstm_seq_bwd: null descriptor");
     return lstm_seq_bwd(*d, *g, S(stream));
 }
+int mmqg_frame_cnn_fwd(const mmqg_frame_cnn* d, mmqg_stream stream) {
+    MMQG_REQUIRE(d, "mmqg_frame_cnn_fwd: null descriptor");
+    return frame_cnn_fwd(*d, S(stream));
+}
+int mmqg_frame_cnn_bwd(const mmqg_frame_cnn* d, const mmqg_frame_cnn_grad* g, mmqg_stream stream) {
+    MMQG_REQUIRE(d && g, "mmqg_frame_cnn_bwd: null descriptor");
+    return frame_cnn_bwd(*d, *g, S(stream));
+}
 int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream) {
     MMQG_REQUIRE(d, "mmqg_decoder_seq_fwd: null descriptor");
     return decoder_seq_fwd(*d, S(stream));

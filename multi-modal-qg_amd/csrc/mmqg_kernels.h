@@ -96,6 +96,10 @@ int axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s);
 int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int rows, int cols,
                      hipStream_t s);
 
+// ---- cnn.hip --------------------------------------------------------------------------
+int frame_cnn_fwd(const mmqg_frame_cnn& d, hipStream_t s);
+int frame_cnn_bwd(const mmqg_frame_cnn& d, const mmqg_frame_cnn_grad& g, hipStream_t s);
+
 // ---- adam.hip -------------------------------------------------------------------------
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps,
               const int32_t* step, float grad_scale, hipStream_t s);

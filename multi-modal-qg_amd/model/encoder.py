@@ -86,12 +86,28 @@ class VideoConvLstmEncoder(nn.Module):
         self.lstm = LSTMParams(video_emb_dim, hidden_dim, 1)
         self.initialise_weights()
 
-    # -- CNN stage (PyTorch-ROCm ops) ------------------------------------------------------
+    # -- CNN stage ---------------------------------------------------------------------------
     def cnn_features(self, frames_btchw, n_frames=None):
         """(B,T,C,H,W) frames, already in the layout the reference's ``view`` produces ->
-        (B,T,flatten).  ReLU comes BEFORE BatchNorm, as at encoder.py:64-65."""
+        (B,T,flatten).  ReLU comes BEFORE BatchNorm, as at encoder.py:64-65.  The reference's
+        hyper-parameters (3x3 kernels, stride 1: config.py:66-67) run in the HIP frame-CNN kernels;
+        any other kernel size / stride takes PyTorch-ROCm's convolution ops."""
         B, T = frames_btchw.shape[:2]
         dev = frames_btchw.device
+        ops.require_device(frames_btchw)
+        if self.kernel_sz == 3 and self.stride == 1:
+            params = []
+            for i in (1, 2, 3, 4):
+                conv, bn = getattr(self, f"conv{i}"), getattr(self, f"bn{i}")
+                params += [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+            bn = self.bn1
+            z = ops.FrameCNNFn.apply(frames_btchw, n_frames, self.training, bn.eps, bn.momentum,
+                                     (False, True, False, True), *params)
+            if self.training:
+                with torch.no_grad():
+                    for i in (1, 2, 3, 4):
+                        getattr(self, f"bn{i}").num_batches_tracked += B
+            return z.reshape(B, T, -1)
         valid = (torch.arange(T, device=dev).view(1, -1) < n_frames.view(-1, 1).to(dev)) if n_frames is not None \
             else torch.ones(B, T, dtype=torch.bool, device=dev)
         x = frames_btchw

@@ -303,5 +303,81 @@ class LSTMSeqFn(torch.autograd.Function):
         return (dx, dh0, dc0, None, None, None, *dparams)
 
 
+class FrameCNNFn(torch.autograd.Function):
+    """The conv3x3 -> ReLU -> per-question BatchNorm (-> 3x3/3 max-pool) blocks of
+    VideoConvLstmEncoder (reference encoder.py:40-50,64-67) in the HIP frame-CNN kernels.
+    frames (B,T,C,H,W) in the reference's view layout; blocks: [(pool, w, bias, gamma, beta,
+    running_mean, running_var)]; returns the last block's output (B*T, C', h', w').  Training
+    mode advances the running statistics in place, once per question."""
+
+    @staticmethod
+    def forward(ctx, frames, n_frames, training, eps, momentum, pools, *params):
+        frames = _f32c(frames)
+        B, T, Cin, H, W = frames.shape
+        nb = len(pools)
+        if nb > _lib.CNN_MAX_BLOCKS or len(params) != 6 * nb:
+            raise ValueError("FrameCNNFn: expected 6 tensors per block and at most %d blocks" % _lib.CNN_MAX_BLOCKS)
+        dev, N = frames.device, B * T
+        nf = None if n_frames is None else n_frames.to(device=dev, dtype=torch.int32).clamp(0, T).contiguous()
+        d = _lib.FrameCnn(B=B, T=T, Cin=Cin, H=H, W=W, n_blocks=nb, training=int(bool(training)), eps=float(eps),
+                          momentum=float(momentum), frames=ptr(frames), n_frames=ptr(nf))
+        keep, h, w, cin = [frames, nf], H, W, Cin
+        for i in range(nb):
+            wt, bias, gamma, beta, rmean, rvar = (_f32c(t) for t in params[6 * i:6 * i + 6])
+            cout = wt.shape[0]
+            if tuple(wt.shape) != (cout, cin, 3, 3):
+                raise ValueError(f"FrameCNNFn: block {i} weight {tuple(wt.shape)} is not ({cout},{cin},3,3)")
+            ho, wo = h - 2, w - 2
+            hz, wz = (ho // 3, wo // 3) if pools[i] else (ho, wo)
+            if min(ho, wo, hz, wz) < 1:
+                raise ValueError("FrameCNNFn: image too small for the CNN")
+            y = torch.empty(N, cout, ho, wo, device=dev)
+            z = torch.empty(N, cout, hz, wz, device=dev)
+            am = torch.empty(N, cout, hz, wz, device=dev, dtype=torch.uint8) if pools[i] else None
+            stats = torch.empty(B, cout, 2, device=dev, dtype=torch.float64)
+            small = torch.empty(4, B, cout, device=dev)
+            blk = d.block[i]
+            blk.cout, blk.pool = cout, int(bool(pools[i]))
+            blk.w, blk.bias, blk.gamma, blk.beta = ptr(wt), ptr(bias), ptr(gamma), ptr(beta)
+            blk.running_mean, blk.running_var = ptr(rmean), ptr(rvar)
+            blk.y, blk.z, blk.argmax, blk.stats = ptr(y), ptr(z), ptr(am), ptr(stats)
+            blk.mean, blk.invstd, blk.scale, blk.shift = (ptr(small[j]) for j in range(4))
+            keep += [wt, bias, gamma, beta, rmean, rvar, y, z, am, stats, small]
+            h, w, cin = hz, wz, cout
+        check(_lib.load().mmqg_frame_cnn_fwd(C.byref(d), _stream()), "frame_cnn_fwd")
+        ctx.desc, ctx.keep, ctx.nb, ctx.training = d, keep, nb, bool(training)
+        ctx.shapes = [tuple(params[6 * i].shape) for i in range(nb)]
+        return keep[-4].view(N, cin, h, w)
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        if not ctx.training:
+            raise _lib.BackendError("mmqg: the frame CNN's backward is defined for training mode (batch statistics)")
+        d, nb = ctx.desc, ctx.nb
+        dfeat = _f32c(dfeat)
+        dev = dfeat.device
+        N = d.B * d.T
+        ymax, xmax, h, w, cin = 0, 0, d.H, d.W, d.Cin
+        for i in range(nb):
+            cout, ho, wo = d.block[i].cout, h - 2, w - 2
+            ymax = max(ymax, N * cout * ho * wo)
+            if i > 0:
+                xmax = max(xmax, N * cin * h * w)
+            h, w = (ho // 3, wo // 3) if d.block[i].pool else (ho, wo)
+            cin = cout
+        dconv = torch.empty(max(ymax, 1), device=dev)
+        dz = torch.empty(max(xmax, 1), device=dev)
+        g = _lib.FrameCnnGrad(dfeat=ptr(dfeat), dconv=ptr(dconv), dz=ptr(dz))
+        grads = []
+        for i in range(nb):
+            cout = d.block[i].cout
+            gw = torch.zeros(ctx.shapes[i], device=dev)
+            small = torch.zeros(3, cout, device=dev)
+            g.dw[i], g.dbias[i], g.dgamma[i], g.dbeta[i] = ptr(gw), ptr(small[0]), ptr(small[1]), ptr(small[2])
+            grads += [gw, small[0], small[1], small[2], None, None]
+        check(_lib.load().mmqg_frame_cnn_bwd(C.byref(d), C.byref(g), _stream()), "frame_cnn_bwd")
+        return (None, None, None, None, None, None, *grads)
+
+
 def lstm_seq(x, h0, c0, params: Sequence[torch.Tensor], dropout_p: float, training: bool, seed: int):
     return LSTMSeqFn.apply(x, h0, c0, dropout_p, training, seed, *params)

@@ -84,6 +84,7 @@ class BatchedTrainer:
         # the GPU-side dependency chain, not by the host) and keep RCCL entirely outside stream capture
         self.use_graph = use_graph and self.world == 1
         self._graph = None
+        self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
         self._dec_reduced = False
         self._side = torch.cuda.Stream(device=self.dev)
         self.reducer = GradReducer(self.flat_g, trainer_buckets(self.segments, self.n_params), self.pg)
@@ -276,6 +277,63 @@ class BatchedTrainer:
             d.seed = self.seed
         self._graph = None            # kernel arguments are frozen into captured graphs
 
+    # ------------------------------------------------------------------------- frame CNN
+    def _ensure_cnn(self, chw: Tuple[int, int, int]) -> None:
+        """Static buffers + descriptor of the HIP frame CNN (encoder.py:40-50,64-67) for raw
+        (C,H,W) frames, time-major so that the last block writes straight into the frame LSTM's
+        input ``feats`` and reads its gradient from ``dfeats``."""
+        if self._cnn_shape == chw:
+            return
+        vid, B, Tf, dev = self.video, self.B, self.Tf, self.dev
+        if vid.kernel_sz != 3 or vid.stride != 1:
+            raise _lib.BackendError("mmqg: the batched trainer's frame CNN covers the reference's 3x3 / stride-1 "
+                                    "convolutions (config.py:66-67)")
+        Cin, Hh, Ww = chw
+        N = B * Tf
+        d = _lib.FrameCnn(B=B, T=Tf, Cin=Cin, H=Hh, W=Ww, n_blocks=4, training=1, time_major=1,
+                          eps=float(vid.bn1.eps), momentum=float(vid.bn1.momentum))
+        g = _lib.FrameCnnGrad()
+        w = self.ws
+        w["raw"] = torch.zeros(Tf, B, Cin, Hh, Ww, device=dev)
+        d.frames, d.n_frames = w["raw"].data_ptr(), w["n_frames"].data_ptr()
+        keep, h, wd, cin, ymax, xmax = [], Hh, Ww, Cin, 1, 1
+        for i, pool in enumerate((False, True, False, True)):
+            conv, bn = getattr(vid, f"conv{i + 1}"), getattr(vid, f"bn{i + 1}")
+            cout, ho, wo = conv.out_channels, h - 2, wd - 2
+            hz, wz = (ho // 3, wo // 3) if pool else (ho, wo)
+            if min(ho, wo, hz, wz) < 1:
+                raise ValueError(f"frames of {Hh}x{Ww} are too small for the four-block CNN")
+            ymax = max(ymax, N * cout * ho * wo)
+            if i > 0:
+                xmax = max(xmax, N * cin * h * wd)
+            last = i == 3
+            if last and cout * hz * wz != self.Fin:
+                raise ValueError(f"CNN output width {cout * hz * wz} != frame LSTM input {self.Fin} "
+                                 f"(flatten_dim / video_emb_dim, config.py:69)")
+            y = torch.empty(N, cout, ho, wo, device=dev)
+            z = w["feats"] if last else torch.empty(N, cout, hz, wz, device=dev)
+            am = torch.empty(N, cout, hz, wz, device=dev, dtype=torch.uint8) if pool else None
+            stats = torch.empty(B, cout, 2, device=dev, dtype=torch.float64)
+            small = torch.empty(4, B, cout, device=dev)
+            blk = d.block[i]
+            blk.cout, blk.pool = cout, int(pool)
+            blk.w, blk.bias, blk.gamma, blk.beta = (t.data_ptr() for t in (conv.weight, conv.bias, bn.weight, bn.bias))
+            blk.running_mean, blk.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            blk.y, blk.z, blk.argmax, blk.stats = y.data_ptr(), z.data_ptr(), ptr(am), stats.data_ptr()
+            blk.mean, blk.invstd, blk.scale, blk.shift = (small[j].data_ptr() for j in range(4))
+            g.dw[i], g.dbias[i] = conv.weight.grad.data_ptr(), conv.bias.grad.data_ptr()
+            g.dgamma[i], g.dbeta[i] = bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr()
+            keep += [y, z, am, stats, small]
+            h, wd, cin = hz, wz, cout
+        w["cnn_dconv"], w["cnn_dz"] = torch.empty(ymax, device=dev), torch.empty(xmax, device=dev)
+        g.dfeat, g.dconv, g.dz = w["dfeats"].data_ptr(), w["cnn_dconv"].data_ptr(), w["cnn_dz"].data_ptr()
+        self.d_cnn, self.g_cnn, self._cnn_keep, self._cnn_shape = d, g, keep, chw
+        self._graph = None
+
+    def _bn_buffers_moved(self) -> bool:
+        vid = self.video
+        return any(getattr(vid, f"bn{i}").running_mean.data_ptr() != self.d_cnn.block[i - 1].running_mean for i in (1, 2, 3, 4))
+
     # ------------------------------------------------------------------------------ modes
     def train(self, mode: bool = True):
         self.training = mode
@@ -287,16 +345,20 @@ class BatchedTrainer:
         return self.train(False)
 
     # --------------------------------------------------------------------------- batches
-    def load_batch(self, batch: dict) -> Optional[torch.Tensor]:
+    def load_batch(self, batch: dict) -> None:
         """Copy one batch into the static input buffers.  ``frames``: (B,Tf,Fin) features or
         (B,Tf,C,H,W) raw frames (already in the reference's viewed layout); ``audio`` (B,Tf,Da);
         ``context`` (B,Tc) ids; ``target`` (B,Td) ids; ``ctx_len``/``tgt_len``/``n_frames`` (B,).
-        Returns the raw-frame tensor when the CNN stage must run (else None)."""
+        Raw frames switch the HIP frame CNN on for the following forward / backward."""
         w, B = self.ws, self.B
         frames = batch["frames"]
-        raw = None
-        if frames.dim() == 5:
-            raw = frames.to(self.dev)
+        self._cnn_on = frames.dim() == 5
+        if self._cnn_on:
+            self._ensure_cnn(tuple(frames.shape[2:]))
+            if self._bn_buffers_moved():          # load_state_dict keeps storage; .to()/re-assignment does not
+                self._cnn_shape = None
+                self._ensure_cnn(tuple(frames.shape[2:]))
+            w["raw"].copy_(frames.to(self.dev).transpose(0, 1))
         else:
             w["feats"].copy_(frames.to(self.dev).transpose(0, 1))
         nf = batch["n_frames"].to(self.dev)
@@ -316,7 +378,6 @@ class BatchedTrainer:
         va = w["values"][:, self.off_audio:self.off_video].view(B, self.Lav, self.Da)
         keep = (torch.arange(audio.shape[1], device=self.dev).view(1, -1) < nf.view(-1, 1)).unsqueeze(-1)
         va[:, :audio.shape[1]].copy_(audio * keep)
-        return raw
 
     # ------------------------------------------------------------------------ one step
     # Two HIP streams: the recurrent time loops are latency-bound chains of small launches, the
@@ -342,6 +403,9 @@ class BatchedTrainer:
         emb = self.dec.emb_layer.weight
         with self._fork():
             s = ops._stream()
+            if self._cnn_on:
+                self.d_cnn.training = int(training)
+                check(lib.mmqg_frame_cnn_fwd(C.byref(self.d_cnn), s), "frame_cnn_fwd")
             check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_vid), s), "lstm_seq_fwd(frames)")
             ops.embedding_fwd(emb, w["ids_d"], w["xemb_d"].view(-1, self.E))
             self.d_dec.phase = 1
@@ -393,6 +457,8 @@ class BatchedTrainer:
                 self._dec_reduced = True
             self.g_vid.phase = 0
             check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s2), "lstm_seq_bwd(frames)")
+            if self._cnn_on:
+                check(lib.mmqg_frame_cnn_bwd(C.byref(self.d_cnn), C.byref(self.g_cnn), s2), "frame_cnn_bwd")
         self.g_dec.phase = 0
         self.g_text.phase = 1
         check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, loop)")
@@ -448,23 +514,21 @@ class BatchedTrainer:
     def forward_backward(self, batch: Optional[dict] = None):
         """zero_grad + forward + loss + backward for the batch already loaded (or ``batch``).
         Gradients are left in ``flat_g`` / every ``param.grad``; returns the loss tensor."""
-        raw = self.load_batch(batch) if batch is not None else None
+        if batch is not None:
+            self.load_batch(batch)
         self.flat_g.zero_()
-        feats = None
-        if raw is not None:
-            # CNN stage on PyTorch-ROCm ops with autograd; its output feeds the HIP frame LSTM
-            with torch.enable_grad():
-                feats = self.video.cnn_features(raw, self.ws["n_frames"]).transpose(0, 1).contiguous()
-            self.ws["feats"].copy_(feats.detach())
         self._forward(self.training)
         self._loss_and_backward()
-        if feats is not None:
-            feats.backward(self.ws["dfeats"])
+        self._count_bn_batches()
         return self.ws["loss"]
+
+    def _count_bn_batches(self):
+        if self._cnn_on and self.training:                      # BatchNorm2d.num_batches_tracked: one per question
+            torch._foreach_add_([getattr(self.video, f"bn{i}").num_batches_tracked for i in (1, 2, 3, 4)], self.B)
 
     def step(self, batch: Optional[dict] = None):
         """One full training iteration (train.py:149-181).  Returns the loss tensor (device)."""
-        if self.use_graph and batch is not None and batch["frames"].dim() != 5:
+        if self.use_graph and batch is not None:
             return self._graph_step(batch)
         loss = self.forward_backward(batch)
         self._allreduce()
@@ -479,12 +543,20 @@ class BatchedTrainer:
 
     def _graph_step(self, batch):
         self.load_batch(batch)
+        if self._graph is not None and self._graph_cnn != self._cnn_on:
+            self._graph = None                                  # raw frames <-> features: different launch sequence
         if self._graph is None:
+            self._graph_cnn = self._cnn_on
             warm = torch.cuda.Stream()
             warm.wait_stream(torch.cuda.current_stream())
+            bn_stats = [b for i in (1, 2, 3, 4) for b in (getattr(self.video, f"bn{i}").running_mean,
+                                                          getattr(self.video, f"bn{i}").running_var)] if self._cnn_on else []
+            saved = [b.clone() for b in bn_stats]
             with torch.cuda.stream(warm):      # warm-up outside capture (lazy code-object loads)
                 self._graph_body()
             torch.cuda.current_stream().wait_stream(warm)
+            for b, v in zip(bn_stats, saved):  # the warm-up pass must not count as a training step
+                b.copy_(v)
             torch.cuda.synchronize()
             # two graphs: [zero, forward, loss, backward] (with its internal fork/join branches) and
             # [Adam]; the gradient all-reduce sits between them (RCCL is not captured)
@@ -495,6 +567,7 @@ class BatchedTrainer:
             with torch.cuda.graph(self._graph_adam, pool=self._graph.pool(), capture_error_mode="thread_local"):
                 self._adam()
         self._graph.replay()
+        self._count_bn_batches()
         self._allreduce()
         self._graph_adam.replay()
         return self.ws["loss"]
@@ -511,17 +584,15 @@ class BatchedTrainer:
         logits (max_len,B,V) or None).  Tokens after <end> are still produced; use
         ``truncate_at_end`` for evaluate.py's stopping rule."""
         T = max_len or self.Td
-        raw = self.load_batch(batch)
-        if raw is not None:
-            was = self.video.training
-            self.video.eval()
-            self.ws["feats"].copy_(self.video.cnn_features(raw, self.ws["n_frames"]).transpose(0, 1))
-            self.video.train(was)
+        self.load_batch(batch)
         lib, w = _lib.load(), self.ws
         L, B, H, V, E = self.L, self.B, self.H, self.V, self.E
         s = ops._stream()
         for d in (self.d_vid, self.d_text):
             d.training = 0
+        if self._cnn_on:
+            self.d_cnn.training = 0
+            check(lib.mmqg_frame_cnn_fwd(C.byref(self.d_cnn), s), "frame_cnn_fwd")
         self.d_text.dropout_p = 0.0
         emb = self.dec.emb_layer.weight
         check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_vid), s), "lstm_seq_fwd(frames)")
@@ -573,12 +644,6 @@ class BatchedTrainer:
 
     @torch.no_grad()
     def forward_only(self, batch: dict, training: bool = False) -> torch.Tensor:
-        raw = self.load_batch(batch)
-        if raw is not None:
-            was = self.video.training
-            self.video.train(training)
-            feats = self.video.cnn_features(raw, self.ws["n_frames"]).transpose(0, 1)
-            self.video.train(was)
-            self.ws["feats"].copy_(feats)
+        self.load_batch(batch)
         self._forward(training)
         return self.logits()

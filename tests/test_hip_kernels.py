@@ -476,3 +476,91 @@ def test_sequence_with_rows_that_never_start(mm):
     assert float(y[:, 0].abs().sum()) == 0 and float(y[2:, 2].abs().sum()) == 0           # zero rows past the length
     assert float(y[:2, 2].abs().sum()) > 0 and float(gates[:, :, 0].abs().sum()) == 0
     assert torch.equal(hs[:, T, 2], hs[:, 2, 2])                                           # row 2 frozen after 2 steps
+
+
+# ------------------------------------------------------------------------------- frame CNN
+def _cnn_params(cin, seed, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    vid, chans = {}, [cin, 4, 6, 8, 10]
+    for i in range(1, 5):
+        ci, co = chans[i - 1], chans[i]
+        vid[f"conv{i}.weight"] = (torch.randn(co, ci, 3, 3, generator=g, dtype=dtype) / (3.0 * ci ** 0.5))
+        vid[f"conv{i}.bias"] = torch.randn(co, generator=g, dtype=dtype) * 0.1
+        vid[f"bn{i}.weight"] = 1.0 + 0.3 * torch.randn(co, generator=g, dtype=dtype)     # some gammas may be < 0
+        vid[f"bn{i}.bias"] = 0.2 * torch.randn(co, generator=g, dtype=dtype)
+        vid[f"bn{i}.running_mean"] = 0.1 * torch.randn(co, generator=g, dtype=dtype)
+        vid[f"bn{i}.running_var"] = 0.5 + torch.rand(co, generator=g, dtype=dtype)
+    vid["bn2.weight"][0] = -0.7                                                         # pooling after a negative scale
+    return vid
+
+
+def _cnn_hip(ops, vid, frames, n_frames, training):
+    params = []
+    for i in range(1, 5):
+        params += [vid[f"conv{i}.weight"], vid[f"conv{i}.bias"], vid[f"bn{i}.weight"], vid[f"bn{i}.bias"],
+                   vid[f"bn{i}.running_mean"], vid[f"bn{i}.running_var"]]
+    return ops.FrameCNNFn.apply(frames, n_frames, training, 1e-5, 0.1, (False, True, False, True), *params)
+
+
+@pytest.mark.parametrize("B,T,Cin,HW,ragged", [(3, 5, 3, 40, True), (2, 4, 3, 56, False), (1, 3, 2, 41, True),
+                                               (4, 8, 3, 112, True)])
+def test_frame_cnn_forward_backward_and_running_stats(mm, B, T, Cin, HW, ragged):
+    """conv3x3 -> ReLU -> per-question BatchNorm (-> max-pool) x4 (encoder.py:40-50,64-67) against the
+    float64 oracle: features, every parameter gradient, the running statistics after the step."""
+    _lib, ops = mm
+    from oracle import mmqg_oracle as O
+    g = torch.Generator().manual_seed(B * 100 + HW)
+    frames = torch.randn(B, T, Cin, HW, HW, generator=g, dtype=torch.float64)
+    n_frames = torch.tensor([max(1, T - 2 * b) for b in range(B)]) if ragged else torch.full((B,), T)
+    valid = (torch.arange(T).view(1, -1) < n_frames.view(-1, 1))
+    frames = frames * valid.view(B, T, 1, 1, 1)                                          # padding frames are zeros
+    vid64 = _cnn_params(Cin, 7)
+    leaf = {k: v.clone().requires_grad_(not k.endswith(("running_mean", "running_var"))) for k, v in vid64.items()}
+    want = O.frame_cnn(leaf, frames, n_frames, True)
+    dfeat = torch.randn(want.shape, generator=g, dtype=torch.float64) * valid.view(B, T, 1)
+    (want * dfeat).sum().backward()
+
+    vid32 = {k: dev(v.float()).requires_grad_(not k.endswith(("running_mean", "running_var"))) for k, v in vid64.items()}
+    fr32, nf = dev(frames.float()), dev(n_frames.int())
+    got = _cnn_hip(ops, vid32, fr32, nf, True)
+    got_flat = got.reshape(B, T, -1)
+    (got_flat * dev(dfeat.float())).sum().backward()
+    torch.cuda.synchronize()
+    close(got_flat * dev(valid.view(B, T, 1).float()), want.detach() * valid.view(B, T, 1), what="features")
+    assert float(got_flat.detach()[~dev(valid)].abs().max() if (~valid).any() else 0.0) == 0.0    # padding frames -> zero rows
+    for k, v in leaf.items():
+        if v.requires_grad:
+            close(vid32[k].grad, v.grad, tol=2e-4, what=f"d{k}")
+        else:
+            close(vid32[k], v, what=k)                                                   # running stats after B questions
+
+    # eval mode: normalise with the (advanced) running statistics, nothing is updated
+    before = {k: v.clone() for k, v in vid32.items() if "running" in k}
+    with torch.no_grad():
+        got_e = _cnn_hip(ops, vid32, fr32, nf, False).reshape(B, T, -1)
+    want_e = O.frame_cnn({k: v.detach() for k, v in leaf.items()}, frames, n_frames, False)
+    close(got_e * dev(valid.view(B, T, 1).float()), want_e * valid.view(B, T, 1), what="eval features")
+    for k, v in before.items():
+        assert torch.equal(v, vid32[k]), k
+
+
+def test_frame_cnn_pool_argmax_ties_pick_first(mm):
+    """Constant frames make every pooling window a tie: the gradient must go to the window's first
+    element (torch max_pool2d's rule), so the weight gradients still match the oracle."""
+    _lib, ops = mm
+    from oracle import mmqg_oracle as O
+    B, T, Cin, HW = 2, 3, 3, 40
+    frames = torch.ones(B, T, Cin, HW, HW, dtype=torch.float64) * torch.arange(1, T + 1).view(1, T, 1, 1, 1)
+    n_frames = torch.full((B,), T)
+    vid64 = _cnn_params(Cin, 11)
+    leaf = {k: v.clone().requires_grad_("running" not in k) for k, v in vid64.items()}
+    want = O.frame_cnn(leaf, frames, n_frames, True)
+    g = torch.Generator().manual_seed(5)
+    dfeat = torch.randn(want.shape, generator=g, dtype=torch.float64)
+    (want * dfeat).sum().backward()
+    vid32 = {k: dev(v.float()).requires_grad_("running" not in k) for k, v in vid64.items()}
+    got = _cnn_hip(ops, vid32, dev(frames.float()), None, True).reshape(B, T, -1)
+    (got * dev(dfeat.float())).sum().backward()
+    close(got, want.detach(), tol=5e-4, what="features")
+    for k in ("conv4.weight", "conv4.bias", "bn4.weight", "bn4.bias"):
+        close(vid32[k].grad, leaf[k].grad, tol=5e-4, what=f"d{k}")

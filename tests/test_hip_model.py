@@ -259,6 +259,27 @@ def test_batched_trainer_two_iterations_match_reference_adam(mm):
                     close(t, want[k], tol=2e-6, what=f"{name}/{k} after iteration {it}")
 
 
+def test_raw_frame_steps_replayed_as_a_graph_equal_eager_steps(mm):
+    """With raw frames the HIP frame CNN is part of the captured step: weights, BatchNorm running
+    statistics and num_batches_tracked after 3 steps must equal the eager run's (the capture's
+    warm-up pass must not advance the running statistics)."""
+    z = load_npz("small_model.npz")
+    batch = collate(small_samples(z))
+    results = []
+    for use_graph in (False, True):
+        c, cfg, vid, text, dec = build_small(mm, z)
+        tr = _trainer(mm, vid, text, dec, batch, use_graph=use_graph).train()
+        losses = [float(tr.step(batch)) for _ in range(3)]
+        results.append((losses, {k: v.clone() for k, v in vid.state_dict().items()}, tr.flat_p.clone()))
+    assert results[0][0] == pytest.approx(results[1][0], rel=1e-5)
+    close(results[1][2], results[0][2], tol=1e-5, what="weights after 3 steps")
+    for k, v in results[0][1].items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(results[1][1][k]) == 3 * batch["target"].shape[0], k
+        else:
+            close(results[1][1][k], v, tol=1e-5, what=k)
+
+
 def _oracle_setup(B, seed, dropout, ragged):
     from mmqg_amd.synthetic import Workload, synthetic_batch
     w = Workload("test", batch=B, n_frames=5, frame_dim=40, audio_dim=12, ctx_len=7, tgt_len=6, vocab=90, emb_dim=20,

@@ -44,7 +44,10 @@ def test_ctypes_structs_match_the_c_layout(lib_mod, tmp_path):
                                                   "ld_attn", "hdrop", "phase"]),
               "mmqg_decoder_seq_grad": ("DecoderSeqGrad", ["dhtop", "ld_ds", "dxemb", "db_hh", "n_text_rows", "dvideo_stride_b", "phase"]),
               "mmqg_decoder_decode": ("DecoderDecode", ["values", "emb_table", "b_hh", "w_out", "start_id", "seed", "target",
-                                                        "ids", "ld_attn", "xemb", "hs", "logits", "keep_logits"])}
+                                                        "ids", "ld_attn", "xemb", "hs", "logits", "keep_logits"]),
+              "mmqg_cnn_block": ("CnnBlock", ["cout", "pool", "w", "running_var", "argmax", "stats", "shift"]),
+              "mmqg_frame_cnn": ("FrameCnn", ["B", "training", "time_major", "eps", "momentum", "frames", "n_frames", "block"]),
+              "mmqg_frame_cnn_grad": ("FrameCnnGrad", ["dfeat", "dz", "dw", "dbias", "dgamma", "dbeta"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mmqg.h"', 'int main(void){']
     for cname, (_, fs) in fields.items():
         src.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
