@@ -177,7 +177,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_pg = world > 1 or (os.environ.get("MMQG_FORCE_DP") == "1" and "RANK" in os.environ)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)
     w = WORKLOADS[a.workload]
@@ -189,7 +190,7 @@ def main():
     batches = [{k: v.to(dev) for k, v in b.items()} for b in batches]
 
     def sync():
-        if world > 1:
+        if use_pg:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -202,7 +203,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     loss_val = float(loss)
-    if world > 1:
+    if use_pg:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -217,7 +218,7 @@ def main():
                       "frame_dim": w.frame_dim, "audio_dim": w.audio_dim, "ctx_len": w.ctx_len, "tgt_len": w.tgt_len,
                       "vocab": w.vocab, "emb_dim": w.emb_dim, "hidden": w.hidden, "layers": w.layers,
                       "attn_widths": [w.text_max_length, w.av_max_length], "dropout": w.dropout,
-                      "parallelism": f"dp{world}", "hipgraph": not a.no_graph},
+                      "parallelism": f"dp{world}", "hipgraph": bool(tr.use_graph)},
            "final_loss": round(loss_val, 4)}
     if rank == 0:
         roof, mfma = kernel_rooflines(tr, w, a.kernel_iters)
@@ -225,7 +226,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-    if world > 1:
+    if use_pg:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:

@@ -8,10 +8,20 @@ The reference has no distributed code at all; this module i
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def exchange_needed(group=None) -> bool:
+    """True when gradients must be all-reduced: more than one rank — or MMQG_FORCE_DP=1 with an
+    initialised process group, which sends a single rank through the same RCCL calls (the way to
+    rehearse the N>1 launch sequence on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("MMQG_FORCE_DP", "0") == "1"
 
 
 def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
@@ -38,10 +48,11 @@ class GradReducer:
         self.buckets = {name: (a, b) for name, a, b in buckets}
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = exchange_needed(group)
         self._pending: List = []
 
     def reduce(self, name: str) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         a, b = self.buckets[name]
         if b > a:
@@ -67,5 +78,5 @@ def trainer_buckets(segments: Dict[str, Tuple[int, int]], n_params: int) -> List
 
 def broadcast_parameters(flat_p: torch.Tensor, group=None, src: int = 0) -> None:
     """Initial replica sync (rank ``src``'s parameters everywhere)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if exchange_needed(group):
         dist.broadcast(flat_p, src=src, group=group)

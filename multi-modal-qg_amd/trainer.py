@@ -29,7 +29,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import K_MAJOR, MN_MAJOR, check, ptr
-from .distributed import GradReducer, broadcast_parameters, trainer_buckets
+from .distributed import GradReducer, broadcast_parameters, exchange_needed, trainer_buckets
 
 _TEXT_STREAM = 1 << 40
 _DEC_STREAM = 2 << 40
@@ -82,13 +82,14 @@ class BatchedTrainer:
         self._describe()
         # hipGraph replay only on a single GPU: eager launches are as fast here (the step is bound by
         # the GPU-side dependency chain, not by the host) and keep RCCL entirely outside stream capture
-        self.use_graph = use_graph and self.world == 1
+        self.distributed = exchange_needed(process_group)
+        self.use_graph = use_graph and not self.distributed
         self._graph = None
         self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
         self._dec_reduced = False
         self._side = torch.cuda.Stream(device=self.dev)
         self.reducer = GradReducer(self.flat_g, trainer_buckets(self.segments, self.n_params), self.pg)
-        if self.world > 1:
+        if self.distributed:
             broadcast_parameters(self.flat_p, self.pg)
 
     # ------------------------------------------------------------------ parameter layout
@@ -450,7 +451,7 @@ class BatchedTrainer:
             self.g_dec.phase = 2
             check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s2), "decoder_seq_bwd(wgrad)")
             ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
-            if self.world > 1 and not torch.cuda.is_current_stream_capturing():
+            if self.distributed and not torch.cuda.is_current_stream_capturing():
                 # the decoder bucket (everything but the embedding) is final here: start its all-reduce
                 # from the side stream so it runs beside the text encoder's backward
                 self.reducer.reduce("dec")
@@ -504,7 +505,7 @@ class BatchedTrainer:
                                  self.step_dev.data_ptr(), scale, s), "adam_step(embedding, 2nd optimizer)")
 
     def _allreduce(self):
-        if self.world > 1:
+        if self.distributed:
             if not self._dec_reduced:
                 self.reducer.reduce("dec")
             self.reducer.reduce("rest")
