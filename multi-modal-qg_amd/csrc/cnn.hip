@@ -1,8 +1,10 @@
 // Frame CNN of VideoConvLstmEncoder (model/encoder.py:40-50,64-67): four blocks of
 //   3x3 valid convolution (stride 1) -> ReLU -> BatchNorm2d, with a 3x3/3 max-pool after blocks 2 and 4.
 // Channel counts are tiny (3 -> 4 -> 6 -> 8 -> 10), so this is memory-bound element-wise work, not a
-// GEMM: direct convolution, one thread per output pixel computing every output channel, weights in
-// LDS.  BatchNorm statistics are per QUESTION (the reference feeds one question's T frames as the
+// GEMM: direct convolution.  For the reference's channel counts a thread produces a 1x4 vertical strip
+// of outputs for every output channel (6x3 input patch per input channel loaded once, every load
+// coalesced along x; weights at compile-time offsets through the scalar cache); other channel counts
+// take generic one-pixel-per-thread kernels with the weights in LDS.  BatchNorm statistics are per QUESTION (the reference feeds one question's T frames as the
 // batch, encoder.py:64), gathered by the convolution kernel itself (block reduction + f64 atomics),
 // so a block costs: conv+ReLU+stats, a tiny finalize, normalise(+pool).  Frames past a question's
 // n_frames are excluded from the statistics and produce zero features.
@@ -89,6 +91,92 @@ __global__ __launch_bounds__(256) void conv3x3_relu_stats_kernel(ConvK a) {
     }
 }
 
+// Specialised convolution for compile-time channel counts.  !BWD: y = relu(conv(x) + bias) and the
+// per-question statistics; reads CA = Cin channels of [H][W], writes CB = Cout channels of [H-2][W-2].
+// BWD: dx = full correlation of dconv with the flipped kernels; reads CA = Cout channels of
+// [H-2][W-2] (through a.x), writes CB = Cin channels of [H][W] (through a.y).
+template <int CA, int CB, bool BWD>
+__global__ __launch_bounds__(256) void conv3x3_strip_kernel(ConvK a) {
+    __shared__ float red[4][2 * CB];
+    const int Hi = BWD ? a.H - 2 : a.H, Wi = BWD ? a.W - 2 : a.W;
+    const int Hout = BWD ? a.H : a.H - 2, Wout = BWD ? a.W : a.W - 2;
+    const int off = BWD ? -2 : 0;
+    const int n = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const bool inb = g < ((Hout + 3) >> 2) * Wout;
+    const int ox = inb ? g % Wout : 0, oy0 = inb ? (g / Wout) * 4 : 0;
+    const float* __restrict__ w = a.w;
+    float acc[4][CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const float b0 = BWD ? 0.f : a.bias[cb];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][cb] = b0;
+    }
+    const float* __restrict__ xin = a.x + (int64_t)n * CA * Hi * Wi;
+#pragma unroll
+    for (int ca = 0; ca < CA; ++ca) {
+        float v[6][3];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = oy0 + r + off;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int ix = ox + c + off;
+                const bool ok = inb && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+                v[r][c] = ok ? xin[((int64_t)ca * Hi + iy) * Wi + ix] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float wv = BWD ? w[((ca * CB + cb) * 3 + (2 - dy)) * 3 + (2 - dx)] : w[((cb * CA + ca) * 3 + dy) * 3 + dx];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j][cb] += v[j + dy][dx] * wv;
+                }
+            }
+        }
+    }
+    float* __restrict__ yout = a.y + (int64_t)n * CB * Hout * Wout;
+    if (BWD) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (inb && oy0 + j < Hout) yout[((int64_t)cb * Hout + oy0 + j) * Wout + ox] = acc[j][cb];
+        return;
+    }
+    int b, t; frame_bt(n, a.N, a.T, a.tm, b, t);
+    const bool valid = a.n_frames ? (t < a.n_frames[b]) : true;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (inb && oy0 + j < Hout) {
+                const float r = fmaxf(acc[j][cb], 0.f);
+                yout[((int64_t)cb * Hout + oy0 + j) * Wout + ox] = r;
+                s1 += r; s2 += r * r;
+            }
+        }
+        if (a.stats) {
+            s1 = wave_sum(s1); s2 = wave_sum(s2);
+            if (lane == 0) { red[wave][2 * cb] = s1; red[wave][2 * cb + 1] = s2; }
+        }
+    }
+    if (a.stats && valid) {
+        __syncthreads();
+        if (threadIdx.x < 2 * CB) {
+            const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            atomicAdd(a.stats + ((int64_t)b * CB * 2 + threadIdx.x), (double)s);
+        }
+    }
+}
+
 struct BnFinK {
     const double* stats;       // [B][C][2]
     const float* gamma; const float* beta;
@@ -99,41 +187,50 @@ struct BnFinK {
     int B, T, C, HW; float eps, momentum; int training;
 };
 
-// one block per channel; thread b handles question b, thread 0 then advances the running statistics
-// once per question in batch order (what B sequential reference calls would do)
+// one block per channel; thread b handles question b (statistics parked in LDS), thread 0 then advances
+// the running statistics once per question in batch order (what B sequential reference calls would do)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinK a) {
+    __shared__ float q_mean[256], q_var[256];    // batch mean / unbiased variance of question b (chunk of 256)
+    __shared__ int q_ok[256];
     const int c = blockIdx.x;
-    for (int b = threadIdx.x; b < a.B; b += 256) {
-        float mean, var;
-        const double cnt = (double)(a.n_frames ? a.n_frames[b] : a.T) * a.HW;
-        if (a.training) {
-            const double s1 = a.stats[((int64_t)b * a.C + c) * 2], s2 = a.stats[((int64_t)b * a.C + c) * 2 + 1];
-            const double m = cnt > 0 ? s1 / cnt : 0.0;
-            mean = (float)m;
-            var = cnt > 0 ? (float)fmax(s2 / cnt - m * m, 0.0) : 0.f;
-        } else {
-            mean = a.running_mean[c];
-            var = a.running_var[c];
-        }
-        const float inv = cnt > 0 || !a.training ? 1.0f / sqrtf(var + a.eps) : 0.f;
-        const int64_t i = (int64_t)b * a.C + c;
-        a.mean[i] = mean; a.invstd[i] = inv;
-        a.scale[i] = a.gamma[c] * inv;
-        a.shift[i] = a.beta[c] - mean * a.gamma[c] * inv;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && a.training && a.running_mean) {
-        float rm = a.running_mean[c], rv = a.running_var[c];
-        for (int b = 0; b < a.B; ++b) {
+    float rm = 0.f, rv = 0.f;
+    const bool ema = a.training && a.running_mean;
+    if (threadIdx.x == 0 && ema) { rm = a.running_mean[c]; rv = a.running_var[c]; }
+    for (int b0 = 0; b0 < a.B; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        if (b < a.B) {
+            float mean, var;
             const double cnt = (double)(a.n_frames ? a.n_frames[b] : a.T) * a.HW;
-            if (cnt <= 1) continue;
-            const double s1 = a.stats[((int64_t)b * a.C + c) * 2], s2 = a.stats[((int64_t)b * a.C + c) * 2 + 1];
-            const double m = s1 / cnt, v = fmax(s2 / cnt - m * m, 0.0) * cnt / (cnt - 1);   // unbiased for the running var
-            rm = (1.f - a.momentum) * rm + a.momentum * (float)m;
-            rv = (1.f - a.momentum) * rv + a.momentum * (float)v;
+            q_ok[threadIdx.x] = 0;
+            if (a.training) {
+                const double s1 = a.stats[((int64_t)b * a.C + c) * 2], s2 = a.stats[((int64_t)b * a.C + c) * 2 + 1];
+                const double m = cnt > 0 ? s1 / cnt : 0.0;
+                const double v = cnt > 0 ? fmax(s2 / cnt - m * m, 0.0) : 0.0;
+                mean = (float)m;
+                var = (float)v;
+                if (cnt > 1) { q_ok[threadIdx.x] = 1; q_mean[threadIdx.x] = mean; q_var[threadIdx.x] = (float)(v * cnt / (cnt - 1)); }
+            } else {
+                mean = a.running_mean[c];
+                var = a.running_var[c];
+            }
+            const float inv = cnt > 0 || !a.training ? 1.0f / sqrtf(var + a.eps) : 0.f;
+            const int64_t i = (int64_t)b * a.C + c;
+            a.mean[i] = mean; a.invstd[i] = inv;
+            a.scale[i] = a.gamma[c] * inv;
+            a.shift[i] = a.beta[c] - mean * a.gamma[c] * inv;
         }
-        a.running_mean[c] = rm; a.running_var[c] = rv;
+        __syncthreads();
+        if (threadIdx.x == 0 && ema) {
+            const int nb = min(256, a.B - b0);
+            for (int j = 0; j < nb; ++j) {
+                if (!q_ok[j]) continue;
+                rm = (1.f - a.momentum) * rm + a.momentum * q_mean[j];
+                rv = (1.f - a.momentum) * rv + a.momentum * q_var[j];
+            }
+        }
+        __syncthreads();
     }
+    if (threadIdx.x == 0 && ema) { a.running_mean[c] = rm; a.running_var[c] = rv; }
 }
 
 struct BnApplyK {
@@ -147,11 +244,11 @@ struct BnApplyK {
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyK a) {
     const int Hz = a.pool ? a.Hy / 3 : a.Hy, Wz = a.pool ? a.Wy / 3 : a.Wy;
-    const int64_t total = (int64_t)a.N * a.C * Hz * Wz;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int px = (int)(i % Wz), py = (int)((i / Wz) % Hz), c = (int)((i / ((int64_t)Wz * Hz)) % a.C);
-    const int n = (int)(i / ((int64_t)Wz * Hz * a.C));
+    const int pix = blockIdx.y * 256 + threadIdx.x;             // grid: (frame*channel planes, pixel blocks)
+    if (pix >= Hz * Wz) return;
+    const int n = blockIdx.x / a.C, c = blockIdx.x % a.C;
+    const int px = pix % Wz, py = pix / Wz;
+    const int64_t i = (int64_t)blockIdx.x * Hz * Wz + pix;
     int b, t; frame_bt(n, a.N, a.T, a.tm, b, t);
     const bool valid = a.n_frames ? (t < a.n_frames[b]) : true;
     if (!valid) { a.z[i] = 0.f; if (a.argmax) a.argmax[i] = 0; return; }
@@ -181,25 +278,28 @@ struct BnBwdK {
     int N, T, C, Hy, Wy, pool, B, tm;
 };
 
-// per (question, channel) sums over the pooled domain: every pooled gradient reaches exactly one y element
+// per (question, channel) sums over the pooled domain: every pooled gradient reaches exactly one y element.
+// grid (pixel slices, C, B): a workgroup walks the question's valid frames, so only `slices` workgroups
+// meet on each accumulator
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdK a) {
     __shared__ float red[4][2];
     const int Hz = a.pool ? a.Hy / 3 : a.Hy, Wz = a.pool ? a.Wy / 3 : a.Wy;
-    const int n = blockIdx.z, c = blockIdx.y;
-    int b, t; frame_bt(n, a.N, a.T, a.tm, b, t);
-    const bool valid = a.n_frames ? (t < a.n_frames[b]) : true;
-    if (!valid) return;
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int nf = a.n_frames ? min(a.n_frames[b], a.T) : a.T;
     const float mu = a.mean[(int64_t)b * a.C + c], inv = a.invstd[(int64_t)b * a.C + c];
-    const float* yp = a.y + ((int64_t)n * a.C + c) * a.Hy * a.Wy;
-    const float* dp = a.dz + ((int64_t)n * a.C + c) * Hz * Wz;
-    const uint8_t* ap = a.argmax ? a.argmax + ((int64_t)n * a.C + c) * Hz * Wz : nullptr;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < Hz * Wz; i += gridDim.x * 256) {
-        const float d = dp[i];
-        int yy = i / Wz, xx = i % Wz;
-        if (a.pool) { const int k = ap[i]; yy = yy * 3 + k / 3; xx = xx * 3 + k % 3; }
-        const float xh = (yp[(int64_t)yy * a.Wy + xx] - mu) * inv;
-        s1 += d; s2 += d * xh;
+    for (int t = 0; t < nf; ++t) {
+        const int n = a.tm ? t * a.B + b : b * a.T + t;
+        const float* yp = a.y + ((int64_t)n * a.C + c) * a.Hy * a.Wy;
+        const float* dp = a.dz + ((int64_t)n * a.C + c) * Hz * Wz;
+        const uint8_t* ap = a.argmax ? a.argmax + ((int64_t)n * a.C + c) * Hz * Wz : nullptr;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < Hz * Wz; i += gridDim.x * 256) {
+            const float d = dp[i];
+            int yy = i / Wz, xx = i % Wz;
+            if (a.pool) { const int k = ap[i]; yy = yy * 3 + k / 3; xx = xx * 3 + k % 3; }
+            const float xh = (yp[(int64_t)yy * a.Wy + xx] - mu) * inv;
+            s1 += d; s2 += d * xh;
+        }
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -208,18 +308,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdK a) {
     if (threadIdx.x < 2) {
         const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         atomicAdd(a.sums + ((int64_t)b * a.C + c) * 2 + threadIdx.x, (double)s);
-        atomicAdd((threadIdx.x == 0 ? a.dbeta : a.dgamma) + c, s);
+        atomicAdd((threadIdx.x == 0 ? a.dbeta : a.dgamma) + c, s);      // slices*B adds per channel
     }
 }
 
 // dconv = relu'(y) * gamma*invstd * (dz' - mean(dz') - xhat * mean(dz' xhat)), dz' = routed pooled gradient
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdK a) {
     const int Hz = a.pool ? a.Hy / 3 : a.Hy, Wz = a.pool ? a.Wy / 3 : a.Wy;
-    const int64_t total = (int64_t)a.N * a.C * a.Hy * a.Wy;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int x = (int)(i % a.Wy), yq = (int)((i / a.Wy) % a.Hy), c = (int)((i / ((int64_t)a.Wy * a.Hy)) % a.C);
-    const int n = (int)(i / ((int64_t)a.Wy * a.Hy * a.C));
+    const int pix = blockIdx.y * 256 + threadIdx.x;             // grid: (frame*channel planes, pixel blocks)
+    if (pix >= a.Hy * a.Wy) return;
+    const int n = blockIdx.x / a.C, c = blockIdx.x % a.C;
+    const int x = pix % a.Wy, yq = pix / a.Wy;
+    const int64_t i = (int64_t)blockIdx.x * a.Hy * a.Wy + pix;
     int b, t; frame_bt(n, a.N, a.T, a.tm, b, t);
     const int nf = a.n_frames ? a.n_frames[b] : a.T;
     if (t >= nf) { a.dconv[i] = 0.f; return; }
@@ -250,6 +350,8 @@ struct ConvBwdK {
     float* dx;                 // [N][Cin][H][W] (input-gradient kernel)
     float* dw; float* dbias;   // accumulate (weight-gradient kernel)
     int N, Cin, Cout, H, W;
+    const int32_t* n_frames; int T, tm;
+    int fpw;                   // frames per workgroup (specialised weight-gradient kernel)
 };
 
 __global__ __launch_bounds__(256) void conv3x3_bwd_input_kernel(ConvBwdK a) {
@@ -326,6 +428,82 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(ConvBwdK a) {
         atomicAdd(a.dbias + co, red[0][kMaxC * 9] + red[1][kMaxC * 9] + red[2][kMaxC * 9] + red[3][kMaxC * 9]);
 }
 
+// Specialised weight gradient: workgroup = (a.fpw consecutive frames, group of G output channels); a thread
+// walks 1x4 vertical strips of those frames, loading the 6x3 input patch of each input channel once for the strip's
+// 4 pixels x G channels x 9 taps; block reduction, one atomic per tap.  Padding frames are skipped.
+template <int CI, int CO, int G>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_strip_kernel(ConvBwdK a) {
+    constexpr int NA = G * CI * 9;
+    __shared__ float red[4][NA + G];
+    const int co0 = blockIdx.y * G, Ho = a.H - 2, Wo = a.W - 2;
+    float acc[G][CI][9];
+    float db[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        db[q] = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[q][ci][k] = 0.f;
+    }
+    const int groups = ((Ho + 3) >> 2) * Wo;
+    for (int idx = threadIdx.x; idx < a.fpw * groups; idx += 256) {
+        const int n = blockIdx.x * a.fpw + idx / groups, g = idx % groups;
+        if (n >= a.N) break;
+        int b, t; frame_bt(n, a.N, a.T, a.tm, b, t);
+        if (a.n_frames && t >= a.n_frames[b]) continue;
+        const float* __restrict__ dp = a.dconv + ((int64_t)n * CO + co0) * Ho * Wo;
+        const float* __restrict__ xp = a.x + (int64_t)n * CI * a.H * a.W;
+        const int ox = g % Wo, oy0 = (g / Wo) * 4;
+        float d[4][G];
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[j][q] = (co0 + q < CO && oy0 + j < Ho) ? dp[((int64_t)q * Ho + oy0 + j) * Wo + ox] : 0.f;
+                db[q] += d[j][q];
+            }
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+            float v[6][3];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    v[r][c] = (oy0 + r < a.H) ? xp[((int64_t)ci * a.H + oy0 + r) * a.W + ox + c] : 0.f;
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[q][ci][dy * 3 + dx] += d[j][q] * v[j + dy][dx];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float sum = wave_sum(acc[q][ci][k]);
+                if (lane == 0) red[wave][(q * CI + ci) * 9 + k] = sum;
+            }
+        const float sb = wave_sum(db[q]);
+        if (lane == 0) red[wave][NA + q] = sb;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NA + G; k += 256) {
+        const float sum = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        const int q = k < NA ? k / (CI * 9) : k - NA;
+        if (co0 + q >= CO) continue;
+        if (k < NA) atomicAdd(a.dw + (int64_t)co0 * CI * 9 + k, sum);
+        else atomicAdd(a.dbias + co0 + q, sum);
+    }
+}
+
 __global__ __launch_bounds__(256) void zero_f64_kernel(double* p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0.0;
@@ -350,6 +528,48 @@ int check_cnn(const mmqg_frame_cnn& d, const char* who) {
     return 0;
 }
 
+// the reference's channel pairs (encoder.py:40-49) get the specialised kernels
+bool launch_conv_fwd(const ConvK& c, int pix_blocks_strip, hipStream_t s) {
+#define MMQG_CASE(CA, CB)                                                                                              \
+    if (c.Cin == CA && c.Cout == CB) {                                                                                 \
+        hipLaunchKernelGGL((conv3x3_strip_kernel<CA, CB, false>), dim3(pix_blocks_strip, c.N), dim3(256), 0, s, c);    \
+        return true;                                                                                                   \
+    }
+    MMQG_CASE(3, 4) MMQG_CASE(4, 6) MMQG_CASE(6, 8) MMQG_CASE(8, 10)
+#undef MMQG_CASE
+    return false;
+}
+
+bool launch_conv_bwd_input(const ConvBwdK& k, hipStream_t s) {
+    // the strip kernel reads a.x = dconv (Cout channels of [H-2][W-2]) and writes a.y = dx (Cin channels of [H][W])
+    ConvK c{k.dconv, k.w, nullptr, k.dx, nullptr, nullptr, k.N, 1, k.Cout, k.Cin, k.H, k.W, 0};
+    const int blocks = mmqg::ceil_div(((k.H + 3) / 4) * k.W, 256);
+#define MMQG_CASE(CA, CB)                                                                                              \
+    if (k.Cout == CA && k.Cin == CB) {                                                                                 \
+        hipLaunchKernelGGL((conv3x3_strip_kernel<CA, CB, true>), dim3(blocks, k.N), dim3(256), 0, s, c);               \
+        return true;                                                                                                   \
+    }
+    MMQG_CASE(6, 4) MMQG_CASE(8, 6) MMQG_CASE(10, 8)
+#undef MMQG_CASE
+    return false;
+}
+
+bool launch_conv_wgrad(ConvBwdK k, hipStream_t s) {
+    // small images: several frames per workgroup (about 8 strips per thread) so the block reduction of
+    // the G*Cin*9 accumulators is amortised
+    const int groups = ((k.H - 2 + 3) / 4) * (k.W - 2);
+    k.fpw = std::max(1, std::min(8, 2048 / std::max(groups, 1)));
+    const int wgx = mmqg::ceil_div(k.N, k.fpw);
+#define MMQG_CASE(CI, CO, G)                                                                                           \
+    if (k.Cin == CI && k.Cout == CO) {                                                                                 \
+        hipLaunchKernelGGL((conv3x3_wgrad_strip_kernel<CI, CO, G>), dim3(wgx, (CO + G - 1) / G), dim3(256), 0, s, k);  \
+        return true;                                                                                                   \
+    }
+    MMQG_CASE(3, 4, 4) MMQG_CASE(4, 6, 3) MMQG_CASE(6, 8, 2) MMQG_CASE(8, 10, 2)
+#undef MMQG_CASE
+    return false;
+}
+
 }  // namespace
 
 namespace mmqg {
@@ -368,7 +588,8 @@ int frame_cnn_fwd(const mmqg_frame_cnn& d, hipStream_t s) {
             hipLaunchKernelGGL(zero_f64_kernel, dim3((unsigned)ceil_div64(ns, 256)), dim3(256), 0, s, b.stats, ns);
         }
         ConvK c{x, b.w, b.bias, b.y, d.training ? b.stats : nullptr, d.n_frames, N, d.T, cin, b.cout, h, w, d.time_major};
-        hipLaunchKernelGGL(conv3x3_relu_stats_kernel, dim3(ceil_div(ho * wo, 256), N), dim3(256), 0, s, c);
+        if (!launch_conv_fwd(c, ceil_div(((ho + 3) / 4) * wo, 256), s))
+            hipLaunchKernelGGL(conv3x3_relu_stats_kernel, dim3(ceil_div(ho * wo, 256), N), dim3(256), 0, s, c);
         MMQG_TRY(check_launch("conv3x3_relu_stats"));
         BnFinK f{b.stats, b.gamma, b.beta, b.running_mean, b.running_var, b.mean, b.invstd, b.scale, b.shift, d.n_frames,
                  d.B, d.T, b.cout, ho * wo, d.eps, d.momentum, d.training};
@@ -377,7 +598,7 @@ int frame_cnn_fwd(const mmqg_frame_cnn& d, hipStream_t s) {
         MMQG_TRY(check_launch("bn_finalize"));
         const int hz = b.pool ? ho / 3 : ho, wz = b.pool ? wo / 3 : wo;
         BnApplyK ap{b.y, b.scale, b.shift, b.z, b.pool ? b.argmax : nullptr, d.n_frames, N, d.T, b.cout, ho, wo, b.pool, d.time_major};
-        hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div64((int64_t)N * b.cout * hz * wz, 256)), dim3(256), 0, s, ap);
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(N * b.cout, ceil_div(hz * wz, 256)), dim3(256), 0, s, ap);
         MMQG_TRY(check_launch("bn_apply"));
         x = b.z; h = hz; w = wz; cin = b.cout;
     }
@@ -408,18 +629,21 @@ int frame_cnn_bwd(const mmqg_frame_cnn& d, const mmqg_frame_cnn_grad& g, hipStre
         hipLaunchKernelGGL(zero_f64_kernel, dim3((unsigned)ceil_div64(ns, 256)), dim3(256), 0, s, b.stats, ns);
         BnBwdK k{b.y, dz, b.pool ? b.argmax : nullptr, b.mean, b.invstd, b.gamma, b.stats, g.dgamma[i], g.dbeta[i], g.dconv,
                  d.n_frames, N, d.T, b.cout, ho, wo, b.pool, d.B, d.time_major};
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(std::min(8, ceil_div(hz * wz, 256)), b.cout, N), dim3(256), 0, s, k);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(std::min(8, ceil_div(hz * wz, 1024)), b.cout, d.B), dim3(256), 0, s, k);
         MMQG_TRY(check_launch("bn_bwd_reduce"));
-        hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3((unsigned)ceil_div64((int64_t)N * b.cout * ho * wo, 256)), dim3(256), 0, s, k);
+        hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(N * b.cout, ceil_div(ho * wo, 256)), dim3(256), 0, s, k);
         MMQG_TRY(check_launch("bn_relu_bwd"));
         const float* xin = i == 0 ? d.frames : d.block[i - 1].z;
-        ConvBwdK cb{xin, b.w, g.dconv, g.dz, g.dw[i], g.dbias[i], N, cin, b.cout, h, w};
-        // enough pixel slices to put ~2k workgroups on the chip, each with at least 4 pixels per thread
-        const int slices = std::max(1, std::min(ceil_div(ho * wo, 1024), ceil_div(2048, N * b.cout)));
-        hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(N, b.cout, slices), dim3(256), 0, s, cb);
+        ConvBwdK cb{xin, b.w, g.dconv, g.dz, g.dw[i], g.dbias[i], N, cin, b.cout, h, w, d.n_frames, d.T, d.time_major, 1};
+        if (!launch_conv_wgrad(cb, s)) {
+            // enough pixel slices to put ~2k workgroups on the chip, each with at least 4 pixels per thread
+            const int slices = std::max(1, std::min(ceil_div(ho * wo, 1024), ceil_div(2048, N * b.cout)));
+            hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(N, b.cout, slices), dim3(256), 0, s, cb);
+        }
         MMQG_TRY(check_launch("conv3x3_bwd_weight"));
         if (i > 0) {
-            hipLaunchKernelGGL(conv3x3_bwd_input_kernel, dim3(ceil_div(h * w, 256), N), dim3(256), 0, s, cb);
+            if (!launch_conv_bwd_input(cb, s))
+                hipLaunchKernelGGL(conv3x3_bwd_input_kernel, dim3(ceil_div(h * w, 256), N), dim3(256), 0, s, cb);
             MMQG_TRY(check_launch("conv3x3_bwd_input"));
             dz = g.dz;
         }
