@@ -5,9 +5,9 @@ AudioVideoEncoder (:113-131), AudioEncoder (:8-19), VideoResnetEncoder (:21-29) 
 names, constructor / ``forward`` signatures and state-dict keys.
 
 * LSTMs and the embedding lookup run in the HIP kernels (no CPU path).
-* The four conv+ReLU+BatchNorm blocks of the frame encoder run on PyTorch-ROCm (MIOpen) ops
-  for now; its LSTM stage uses the HIP sequence executor.  ``VideoConvLstmEncoder.forward``
-  also accepts pre-extracted per-frame features (T,D) / (B,T,D) that skip the CNN
+* The four conv+ReLU+BatchNorm(+max-pool) blocks of the frame encoder run in the HIP frame-CNN
+  kernels (``mmqg_frame_cnn_fwd/bwd``) for the reference's 3x3 / stride-1 hyper-parameters; its
+  LSTM stage uses the HIP sequence executor.  ``VideoConvLstmEncoder.forward`` also accepts pre-extracted per-frame features (T,D) / (B,T,D) that skip the CNN
   (BASELINE configs 2-5: ``video_emb_dim`` = feature width, e.g. 2048).
 * AudioEncoder wraps a remote torch.hub VGGish in the reference (encoder.py:12), which cannot
   be fetched offline; here it passes (n_clips,128) feature tensors through unchanged.
