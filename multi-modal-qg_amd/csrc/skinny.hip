@@ -69,9 +69,20 @@ struct SkinnyBatch {
     SkinnyK job[3];      // blockIdx.z selects the job: independent layer-steps of one wavefront diagonal
 };
 
+// tools/skinny_probe.hip compiles this file with MMQG_SKINNY_TRACE to stamp the stages of a workgroup
+#ifdef MMQG_SKINNY_TRACE
+__device__ unsigned long long* g_skinny_trace = nullptr;
+#define MMQG_STAMP(slot)                                                                                          \
+    if (g_skinny_trace && threadIdx.x == 0)                                                                       \
+        g_skinny_trace[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64();
+#else
+#define MMQG_STAMP(slot)
+#endif
+
 template <int MODE, int KS>
 __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
     __shared__ float part[2][KS][16][17];
+    MMQG_STAMP(0)
     const SkinnyK& a = batch.job[blockIdx.z];
     if ((int)blockIdx.y * 16 >= a.M || (int)blockIdx.x * (MODE == MODE_FWD_CELL ? 4 : 16) >= (MODE == MODE_FWD_CELL ? a.H : a.N))
         return;   // jobs of one launch may differ in size
@@ -123,6 +134,7 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
         }
     }
 
+    MMQG_STAMP(1)
     f32x4 acc_p = {0.f, 0.f, 0.f, 0.f}, acc_m = {0.f, 0.f, 0.f, 0.f};
     // The pair loop is unrolled with compile-time pair indices: indexing the kernel-argument array with
     // a run-time value made hipcc fetch the Pair fields with per-lane global loads and a vmcnt(0) wait
@@ -184,7 +196,9 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
         part[0][wave][kq * 4 + r][c] = acc_p[r];
         if (MODE == MODE_BWD_CELL) part[1][wave][kq * 4 + r][c] = acc_m[r];
     }
+    MMQG_STAMP(2)
     __syncthreads();
+    MMQG_STAMP(3)
     const int tid = threadIdx.x;
     if (tid >= 256) { if (MODE != MODE_FWD_CELL) return; }
     const int row = (tid >> 4) & 15, col = tid & 15;
@@ -238,6 +252,7 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
         a.c_out[e] = cc;
         if (a.h_drop) a.h_drop[e] = active ? h * dropout_scale(eff_seed(a.seed, a.seed_off), a.stream_id, (uint64_t)e, a.drop_p) : 0.f;
         if (a.y_out) a.y_out[(int64_t)b * a.y_stride_b + j] = active ? h : 0.f;
+        MMQG_STAMP(4)
         return;
     }
 
@@ -277,6 +292,7 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
         dg[3 * H + j] = dh * tc * go * (1.f - go);
         a.dc[e] = dct * gf;
         a.carry[e] = 0.f;
+        MMQG_STAMP(4)
     }
 }
 
