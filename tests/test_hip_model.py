@@ -498,8 +498,8 @@ def test_train_driver_on_a_tiny_corpus_in_the_reference_formats(mm, tmp_path, ca
         stem = f"v_{q['video_id']}_q_{q['question_id']}_"
         np.save(tmp_path / "frames" / (stem + ".npy"), rng.integers(0, 256, (T, 112, 112, 3), dtype=np.uint8))
         np.save(tmp_path / "audio" / (stem + ".npy"), rng.standard_normal((T, 128)).astype(np.float32))
-    for name in ("train", "val"):
-        json.dump(qs[:4] if name == "train" else qs[4:], open(tmp_path / "data" / f"{name}_questions.json", "w"))
+    for name in ("train", "val", "test"):
+        json.dump(qs[:4] if name == "train" else (qs[4:] if name == "val" else qs[1:6]), open(tmp_path / "data" / f"{name}_questions.json", "w"))
     json.dump(vocab, open(tmp_path / "data" / "vocab.json", "w"))
     json.dump({str(i): w for w, i in vocab.items()}, open(tmp_path / "data" / "index_to_word.json", "w"))
     np.save(tmp_path / "data" / "weight_matrix.npy", rng.standard_normal((len(words), 300)))
@@ -509,6 +509,7 @@ def test_train_driver_on_a_tiny_corpus_in_the_reference_formats(mm, tmp_path, ca
                 "av_model_path": str(tmp_path / "out" / "av_model.pth"), "text_enc_model_path": str(tmp_path / "out" / "text_enc_model.pth"),
                 "dec_model_path": str(tmp_path / "out" / "dec_model.pth"), "learned_weight_path": str(tmp_path / "out" / "learned_weight.pt"),
                 "train_file": str(tmp_path / "data" / "train_questions.json"), "val_file": str(tmp_path / "data" / "val_questions.json"),
+                "test_file": str(tmp_path / "data" / "test_questions.json"),
                 "vocab_file": str(tmp_path / "data" / "vocab.json"), "index_to_word_file": str(tmp_path / "data" / "index_to_word.json"),
                 "weights_matrix_file": str(tmp_path / "data" / "weight_matrix.npy"),
                 "salient_frames_path": str(tmp_path / "frames"), "salient_audio_path": str(tmp_path / "audio"),
@@ -523,6 +524,17 @@ def test_train_driver_on_a_tiny_corpus_in_the_reference_formats(mm, tmp_path, ca
         have = set(os.listdir(tmp_path / "out"))
         assert {"av_model.pth", "text_enc_model.pth", "dec_model.pth", "learned_weight.pt", "last_decoder.pth",
                 "training_state.pt", "config.json"} <= have
+        # evaluate.py's command line on the checkpoints just written: 5 test questions in batches of 2
+        import evaluate_mi355x as ev
+        for flag, strategy, name in (("-l", "greedy", "last_predictions_greedy.json"), ("-b", "sampling", "best_predictions_sampling.json"),
+                                     ("-l", "topk", "last_predictions_topk.json")):
+            preds, bleu, b1, b2, b3 = ev.main(["-c", str(tmp_path / "cfg.json"), "-s", strategy, flag, "--max-frames", "4", "--max-context", "8"])
+            on_disk = json.load(open(tmp_path / "out" / name))
+            assert on_disk == preds and [p["question_id"] for p in preds] == [1, 2, 3, 4, 5]
+            assert all(set(p) == {"question_id", "gt_question", "pred_question"} and "<end>" not in p["pred_question"] for p in preds)
+            assert all(0.0 <= v <= 1.0 + 1e-9 for v in (bleu, b1, b2, b3))
+        greedy = json.load(open(tmp_path / "out" / "last_predictions_greedy.json"))
+        assert greedy == json.load(open(tmp_path / "out" / "last_predictions_topk.json"))      # evaluate.py:96: k = 1
     finally:
         for k, v in saved.items():
             setattr(Config, k, v)

@@ -61,21 +61,13 @@ def run_synthetic(a, world, rank, dev):
         print(f"{world * B * (a.steps - i0) / dt:.1f} questions/s over {a.steps - i0} steps on {world} GPU(s)")
 
 
-def run_real(a, world, rank, dev):
-    from mmqg_amd.data import Compose, Resize, ToFloatTensor, VQGDataset, collate_questions, prepare_sequence
-    from mmqg_amd.distributed import shard_batch
+def build_from_config(cfg, weights, dev):
+    """The three modules as train.py:236-258 / evaluate.py:175-207 construct them, sharing one embedding."""
     import importlib
     enc = importlib.import_module("multi-modal-qg_amd.model.encoder")
     decm = importlib.import_module("multi-modal-qg_amd.model.decoder")
-    cfg = Config(a.config)
-    weights = torch.from_numpy(np.load(cfg.weights_matrix_file)).float()      # kept float (train.py:227 truncates to int)
     emb = torch.nn.Embedding(*weights.shape)
     emb.load_state_dict({"weight": weights})
-    tfm = Compose([ToFloatTensor(), Resize(112)])
-    train_ds = VQGDataset(cfg.train_file, cfg.vocab_file, cfg.index_to_word_file, str(cfg.salient_frames_path),
-                          str(cfg.salient_audio_path), prepare_sequence, tfm)
-    val_ds = VQGDataset(cfg.val_file, cfg.vocab_file, cfg.index_to_word_file, str(cfg.salient_frames_path),
-                        str(cfg.salient_audio_path), prepare_sequence, tfm)
     av = enc.AudioVideoEncoder(cfg.av_in_channels, cfg.av_kernel_sz, cfg.av_stride, cfg.video_hidden_dim, cfg.flatten_dim)
     text = enc.TextEncoder(cfg.text_lstm_layers, cfg.text_lstm_dropout, cfg.text_lstm_hidden_dim, weights.shape[1], emb, dev)
     dec = decm.AttnDecoder(cfg.dec_lstm_layers, cfg.dec_lstm_dropout, cfg.dec_lstm_hidden_dim, weights.shape[0],
@@ -84,6 +76,19 @@ def run_real(a, world, rank, dev):
     dec.mask_mode = cfg.attention_mask_mode
     for m in (av, text, dec):
         m.to(dev)
+    return av, text, dec
+
+
+def run_real(a, world, rank, dev):
+    from mmqg_amd.data import Compose, Resize, ToFloatTensor, VQGDataset, collate_questions, prepare_sequence
+    cfg = Config(a.config)
+    weights = torch.from_numpy(np.load(cfg.weights_matrix_file)).float()      # kept float (train.py:227 truncates to int)
+    tfm = Compose([ToFloatTensor(), Resize(112)])
+    train_ds = VQGDataset(cfg.train_file, cfg.vocab_file, cfg.index_to_word_file, str(cfg.salient_frames_path),
+                          str(cfg.salient_audio_path), prepare_sequence, tfm)
+    val_ds = VQGDataset(cfg.val_file, cfg.vocab_file, cfg.index_to_word_file, str(cfg.salient_frames_path),
+                        str(cfg.salient_audio_path), prepare_sequence, tfm)
+    av, text, dec = build_from_config(cfg, weights, dev)
     B = a.batch or cfg.batch_size
     Tf, Tc, Td = a.max_frames, a.max_context, cfg.question_max_length
     tr = BatchedTrainer(av, text, dec, batch_size=B, n_frames=Tf, ctx_len=Tc, tgt_len=Td, lr=cfg.lr,
