@@ -141,14 +141,15 @@ def cpu_baseline(w, budget_s):
 
     # pick the thread count that serves this small-op workload best (all cores oversubscribe it)
     one(0)
-    best, best_t = None, None
-    for nt in sorted({8, 16, 32, min(64, os.cpu_count() or 8)}):
+    best, best_t, sweep = None, None, {}
+    for nt in sorted({1, 8, 16, 32, min(64, os.cpu_count() or 8)}):
         if nt > (os.cpu_count() or 8):
             continue
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
         one(1)
         el = time.perf_counter() - t0
+        sweep[str(nt)] = round(1.0 / el, 3)
         if best is None or el < best:
             best, best_t = el, nt
     torch.set_num_threads(best_t)
@@ -161,7 +162,8 @@ def cpu_baseline(w, budget_s):
             break
     return {"value": round(n / el, 4), "unit": "questions/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} questions, batch 1, {w.name.split(':')[0]} shapes, fwd+bwd+3xAdam, torch-CPU oracle, "
-                      f"{el:.1f} s after warm-up; thread count chosen by a 1-question sweep over 8/16/32/64", "host_cpus": os.cpu_count()}
+                      f"{el:.1f} s after warm-up; thread count chosen by a 1-question sweep over 1/8/16/32/64",
+            "host_cpus": os.cpu_count(), "one_question_sweep_qps_by_threads": sweep}
 
 
 def main():

@@ -12,10 +12,13 @@
 // the LSTM gate pre-activations x*W_ih^T + h*W_hh^T are produced by one launch.
 //
 // Tiling: 256 threads = 4 wavefronts (2x2).  Two shapes:
-//   BIG   128x128x16, each wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs)
+//   BIG   128x128x{16,32}, each wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs)
 //   SMALL  64x64x32,  each wave 32x32 = 1 MFMA tile; used with split-K (atomic f32 adds)
 //          for the batch-sized (M<=64) products inside the recurrent loops so that more
 //          than a handful of the 256 CUs get work.
+// Interior tiles of 16-byte-aligned operands run a body whose loaders have no bounds logic at all
+// (plain global_load_dwordx4 per staged float4); only edge tiles and the K tail pay for the checks.
+// That alone took 4096^3 from 104 to 132 TFLOP/s (0.66 -> 0.84 of the fp32 MFMA peak).
 // LDS holds both operands k-major ([k][m] and [k][n], two stages) so an MFMA operand read is
 // one conflict-free ds_read_b32 per lane; global loads are 16 B per lane and are issued for
 // tile t+1 before the MFMAs of tile t, then written to the other LDS stage (one barrier per tile).
@@ -39,6 +42,7 @@ struct GemmArgs {
     int beta;          // 0: overwrite, 1: accumulate
     int split_k;       // >1: every z-slice adds its partial product with f32 atomics
     int vec_a, vec_b, vec_a2, vec_b2;   // operand may be read with aligned 16-B loads
+    int fast;                           // all operands 16-byte aligned: interior tiles load without bounds logic
 };
 
 // One operand tile of ROWS (m or n) x BK (k), staged through registers.
@@ -53,12 +57,22 @@ struct TileLoader {
 
     float4 v[NV];
 
+    // CHECK = false: the whole tile is inside the operand and 16-byte aligned (interior tiles of aligned
+    // operands, the common case) -> NV plain 16-byte loads, no bounds logic in the main loop
+    template <bool CHECK>
     __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int row0, int nrows, int k0, int K,
                                          bool vec) {
         const int t = threadIdx.x;
         if constexpr (KMAJOR) {
             constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
             const int kq = t % F4_PER_ROW, r = t / F4_PER_ROW;
+            if constexpr (!CHECK) {
+#pragma unroll
+                for (int p = 0; p < NV; ++p) {
+                    const float4 x = *reinterpret_cast<const float4*>(P + (int64_t)(row0 + p * ROWS_PER_PASS + r) * ld + k0 + 4 * kq);
+                    v[p] = x;
+                }
+            } else {
 #pragma unroll
             for (int p = 0; p < NV; ++p) {
                 const int row = row0 + p * ROWS_PER_PASS + r;
@@ -77,10 +91,18 @@ struct TileLoader {
                 }
                 v[p] = x;
             }
+            }
         } else {
             constexpr int F4_PER_K = ROWS / 4;
             constexpr int K_PER_PASS = 256 / F4_PER_K;
             const int c4 = t % F4_PER_K, kr = t / F4_PER_K;
+            if constexpr (!CHECK) {
+#pragma unroll
+                for (int p = 0; p < NV; ++p) {
+                    const float4 x = *reinterpret_cast<const float4*>(P + (int64_t)(k0 + p * K_PER_PASS + kr) * ld + row0 + 4 * c4);
+                    v[p] = x;
+                }
+            } else {
 #pragma unroll
             for (int p = 0; p < NV; ++p) {
                 const int k = k0 + p * K_PER_PASS + kr;
@@ -98,6 +120,7 @@ struct TileLoader {
                     }
                 }
                 v[p] = x;
+            }
             }
         }
     }
@@ -127,14 +150,13 @@ struct TileLoader {
     }
 };
 
-template <int BM, int BN, int BK, bool A_K, bool B_K>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+template <int BM, int BN, int BK, bool A_K, bool B_K, bool CHECK>
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, float* smem) {
     using LA = TileLoader<BM, BK, A_K>;
     using LB = TileLoader<BN, BK, B_K>;
     constexpr int WTM = BM / 2, WTN = BN / 2;      // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;    // MFMA tiles per wave
     constexpr int A_ELEMS = BK * LA::LD, B_ELEMS = BK * LB::LD;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -160,17 +182,34 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     LA la; LB lb;
-    auto fetch = [&](int kt) {
-        if (kt < nk1) {
-            la.load(p.A, p.lda, m0, p.M, kt * BK, p.K, p.vec_a);
-            lb.load(p.B, p.ldb, n0, p.N, kt * BK, p.K, p.vec_b);
-        } else {
-            la.load(p.A2, p.lda2, m0, p.M, (kt - nk1) * BK, p.K2, p.vec_a2);
-            lb.load(p.B2, p.ldb2, n0, p.N, (kt - nk1) * BK, p.K2, p.vec_b2);
-        }
-    };
+    // operand descriptors as plain locals: a lambda that captured the argument struct by reference made
+    // hipcc keep a copy of it in scratch
+    const float* const A1 = p.A; const float* const B1 = p.B; const float* const A2 = p.A2; const float* const B2 = p.B2;
+    const int lda1 = p.lda, ldb1 = p.ldb, lda2 = p.lda2, ldb2 = p.ldb2, M = p.M, N = p.N, K1 = p.K, K2 = p.K2;
+    const bool va1 = p.vec_a, vb1 = p.vec_b, va2 = p.vec_a2, vb2 = p.vec_b2;
+#define MMQG_FETCH(kt_)                                                                    \
+    do {                                                                                   \
+        const int kt__ = (kt_);                                                            \
+        if (kt__ < nk1) {                                                                  \
+            if (!CHECK && (kt__ + 1) * BK <= K1) {        /* k-tile inside K: no checks */ \
+                la.template load<false>(A1, lda1, m0, M, kt__ * BK, K1, va1);              \
+                lb.template load<false>(B1, ldb1, n0, N, kt__ * BK, K1, vb1);              \
+            } else {                                                                       \
+                la.template load<true>(A1, lda1, m0, M, kt__ * BK, K1, va1);               \
+                lb.template load<true>(B1, ldb1, n0, N, kt__ * BK, K1, vb1);               \
+            }                                                                              \
+        } else {                                                                           \
+            if (!CHECK && (kt__ - nk1 + 1) * BK <= K2) {                                   \
+                la.template load<false>(A2, lda2, m0, M, (kt__ - nk1) * BK, K2, va2);      \
+                lb.template load<false>(B2, ldb2, n0, N, (kt__ - nk1) * BK, K2, vb2);      \
+            } else {                                                                       \
+                la.template load<true>(A2, lda2, m0, M, (kt__ - nk1) * BK, K2, va2);       \
+                lb.template load<true>(B2, ldb2, n0, N, (kt__ - nk1) * BK, K2, vb2);       \
+            }                                                                              \
+        }                                                                                  \
+    } while (0)
 
-    fetch(kt_begin);
+    MMQG_FETCH(kt_begin);
     la.store(smem);
     lb.store(smem + A_ELEMS);
     __syncthreads();
@@ -181,7 +220,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         const float* As = smem + cur * (A_ELEMS + B_ELEMS);
         const float* Bs = As + A_ELEMS;
         const bool more = kt + 1 < kt_end;
-        if (more) fetch(kt + 1);
+        if (more) MMQG_FETCH(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float a[TM], b[TN];
@@ -226,6 +265,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
             }
         }
     }
+}
+
+#undef MMQG_FETCH
+
+template <int BM, int BN, int BK, bool A_K, bool B_K>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+    using LA = TileLoader<BM, BK, A_K>;
+    using LB = TileLoader<BN, BK, B_K>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LA::LD + LB::LD)];
+    // interior tiles of aligned operands (p.fast, decided on the host) skip every bounds check of the loaders
+    const bool interior = p.fast && (int)(blockIdx.y + 1) * BM <= p.M && (int)(blockIdx.x + 1) * BN <= p.N;
+    if (interior) gemm_body<BM, BN, BK, A_K, B_K, false>(p, smem);
+    else gemm_body<BM, BN, BK, A_K, B_K, true>(p, smem);
 }
 
 template <int BM, int BN, int BK>
@@ -286,7 +338,12 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
     // has at least ~2 workgroups per CU, keeping >= 8 k-tiles per slice.  MMQG_GEMM_HEUR=1 restores the
     // round-1 rule (big tile only for >= 96 tiles, split-K only on the small tile).
     static const int heur = env_int("MMQG_GEMM_HEUR", 2);
-    static const int big_bk = env_int("MMQG_GEMM_BIG_BK", 32);
+    // k-tile of the 128x128 shape: 32 (one barrier per 64 MFMAs, 2 workgroups per CU) suits the k-major
+    // x k-major products with short K (hoisted input products, vocabulary projection); 16 (33 KB of LDS, 3
+    // workgroups per CU) measured faster for the n-major-B products (data / weight gradients, mostly split-K).
+    // MMQG_GEMM_BIG_BK=16|32 forces one of them.
+    static const int big_bk_env = env_int("MMQG_GEMM_BIG_BK", 0);
+    const int big_bk = big_bk_env ? big_bk_env : (b_layout == MMQG_MN_MAJOR ? 16 : 32);
     const int64_t big_tiles = (int64_t)ceil_div(M, 128) * ceil_div(N, 128);
     bool small;
     if (heur == 1) small = (M <= 64) || (N <= 64) || big_tiles < 96;
@@ -309,6 +366,8 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
     if (split_k > max_split) split_k = max_split;
     if (split_k > nk) split_k = nk > 0 ? nk : 1;
     a.split_k = split_k;
+    static const int no_fast = env_int("MMQG_GEMM_NO_FAST", 0);
+    a.fast = !no_fast && a.vec_a && a.vec_b && (!A2 || (a.vec_a2 && a.vec_b2));
     if (split_k > 1 && !beta) {
         // partial products are added atomically, so the destination must start from zero
         if (memset_api && ldc == N) {

@@ -20,7 +20,7 @@ def t(name, al, bl, M, N, K, iters=30):
     us = e0.elapsed_time(e1) / iters * 1e3
     print(f"{name:34s} M={M:5d} N={N:5d} K={K:5d}  {us:8.1f} us  {2*M*N*K/us/1e6:6.1f} TFLOP/s", flush=True)
 
-print("BIG_BK", os.environ.get("MMQG_GEMM_BIG_BK", "16"))
+print("BIG_BK", os.environ.get("MMQG_GEMM_BIG_BK", "per layout"))
 t("vocab fwd  (NT)", 0, 0, 1280, 10000, 512)
 t("vocab dgrad (NN)", 0, 1, 1280, 512, 10000)
 t("vocab wgrad (TN)", 1, 1, 10000, 512, 1280)
