@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMQG_ABI_VERSION 1
+#define MMQG_ABI_VERSION 2
 #define MMQG_MAX_LAYERS 8
 
 typedef void* mmqg_stream; /* hipStream_t */
@@ -233,6 +233,10 @@ typedef struct {
     int32_t phase;                                  /* 0 = everything; 1 = time loop + initial-state and value
                                                        gradients (what the encoders' backward needs); 2 = dxemb,
                                                        weight and bias gradients */
+    /* optional [L][B][H] workspace: with it the time loop forms the recurrent product dgates_l(t) * W_hh_l
+     * one step ahead of its use, as an extra job of a launch that is on the dependent chain anyway, so the
+     * cell kernels of the chain carry only the operand pair that really is late. */
+    float* dh_pre;
 } mmqg_decoder_seq_grad;
 
 /* mmqg_decoder_decode: the free-running decode loop of validate() / evaluate()

@@ -125,6 +125,7 @@ int lstm_cell_bwd(const CellBwd& f, hipStream_t s) {
     if (f.B == 0) return 0;
     MMQG_REQUIRE(f.gates_act && f.c_prev && f.c_new && f.dh_rec && f.dc && f.dgates, "lstm_cell_bwd: null pointer");
     MMQG_REQUIRE(f.ld_dg >= 4 * f.H, "lstm_cell_bwd: ld_dg < 4H");
+    MMQG_REQUIRE(!f.dh_pre, "lstm_cell_bwd: dh_pre is a fused-kernel input");
     CellBwdK k{f.B, f.H, f.gates_act, f.c_prev, f.c_new, f.dh_rec, f.dh_above, f.above_stride_b,
                f.p, f.seed, f.stream_id, f.seed_off, f.dh_extra, f.extra_stride_b, f.dc, f.dgates, f.ld_dg, f.lens, f.t};
     const int64_t n = (int64_t)f.B * f.H;

@@ -38,6 +38,8 @@ struct CellBwd {
     float p; uint64_t seed; uint64_t stream_id;       // dropout that was applied to that output
     const int32_t* seed_off;
     const float* dh_extra; int64_t extra_stride_b;   // nullable: further gradient of h (only for active rows)
+    const float* dh_pre;                    // nullable [B][H]: part of the recurrent product formed ahead of time
+                                            // (fused skinny kernel only; added for every row)
     float* dc;                              // in/out [B][H]
     float* dgates; int ld_dg;               // out [B][4H]
     const int32_t* lens; int t;
@@ -65,6 +67,11 @@ int skinny_cell_bwd(const SkinnyPair* pairs, int npairs, const CellBwd& f, hipSt
 // up to three independent layer-steps (one wavefront diagonal of a layer stack) in ONE launch
 struct SkinnyFwdJob { SkinnyPair pairs[3]; int npairs; int gates_has_pre; const float* bias1; const float* bias2; CellFwd cell; };
 struct SkinnyBwdJob { SkinnyPair pairs[3]; int npairs; CellBwd cell; };
+struct SkinnyPlainJob { int M, N; SkinnyPair pairs[3]; int npairs; const float* bias; int beta; float* C; int ldc; };
+// up to 3 independent plain products in ONE launch
+int skinny_plain_multi(const SkinnyPlainJob* jobs, int njobs, hipStream_t s);
+// one cell-backward layer-step plus up to 2 independent plain products in ONE launch
+int skinny_cell_bwd_plus(const SkinnyBwdJob& cell, const SkinnyPlainJob* extra, int nextra, hipStream_t s);
 int skinny_cell_fwd_multi(const SkinnyFwdJob* jobs, int njobs, hipStream_t s);
 int skinny_cell_bwd_multi(const SkinnyBwdJob* jobs, int njobs, hipStream_t s);
 int transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s);

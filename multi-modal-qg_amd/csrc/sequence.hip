@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "mmqg_common.h"
 #include "mmqg_kernels.h"
@@ -443,6 +444,12 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
         const SkinnyPair b{g.dscores, ldD, d.w_attn_hT, ldS, ldS, 0};
         fusedb = skinny_usable(&a, 1) && skinny_usable(&b, 1) && (ldD >= ldS);
     }
+    // Look-ahead: the recurrent product dgates_l(t) * W_hh_l is needed by cell (l, t-1), a whole step
+    // after dgates_l(t) exists.  It is formed as an extra (plain) job of the NEXT launch on the dependent
+    // chain — cell (l-1, t), or the dctx product for layer 0 — into dh_pre[l], so the cell kernels on the
+    // chain only carry the operand pair that really is late (K halves for layers 0..L-2, 2048 -> 488 for the
+    // top layer) and those launches fill twice as many CUs.
+    const bool ahead = fusedb && g.dh_pre && T > 1;
     for (int t = T - 1; t >= 0; --t) {
         for (int l = L - 1; l >= 0; --l) {
             const float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;
@@ -466,17 +473,40 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
                 SkinnyPair prs[3];
                 int np = 0;
                 if (t < T - 1) {
-                    prs[np++] = SkinnyPair{g.dgates + (int64_t)l * T * G + (t + 1) * G, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+                    if (ahead) c.dh_pre = g.dh_pre + l * BH;       // formed one launch after cell (l, t+1)
+                    else prs[np++] = SkinnyPair{g.dgates + (int64_t)l * T * G + (t + 1) * G, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
                     if (l == L - 1)
                         prs[np++] = SkinnyPair{g.dscores + (int64_t)(t + 1) * B * ldD, ldD, d.w_attn_hT, ldS, ldS, 0};
                 }
                 if (l < L - 1)
                     prs[np++] = SkinnyPair{g.dgates + (int64_t)(l + 1) * T * G + t * G, 4 * H, d.w_ihT[l + 1], 4 * H, 4 * H, 1};
-                if (np > 0) MMQG_TRY(skinny_cell_bwd(prs, np, c, s));
-                else MMQG_TRY(lstm_cell_bwd(c, s));
-                if (l == 0) {   // dctx(t) = dgates_0(t) * W_ih0[:, E:]
-                    const SkinnyPair pc{dg, 4 * H, d.w_ih0cT, 4 * H, 4 * H, 0};
-                    MMQG_TRY(skinny_plain(B, C, &pc, 1, nullptr, 0, g.dctx + (int64_t)t * B * C, C, s));
+                // product for cell (l+1, t-1): dgates_{l+1}(t) exists since the previous launch
+                SkinnyPlainJob look{};
+                const bool with_look = ahead && t > 0 && l < L - 1;
+                if (with_look) {
+                    look.M = B; look.N = H; look.npairs = 1; look.C = g.dh_pre + (l + 1) * BH; look.ldc = H;
+                    look.pairs[0] = SkinnyPair{g.dgates + (int64_t)(l + 1) * T * G + t * G, 4 * H, d.w_hhT[l + 1], 4 * H, 4 * H, 0};
+                }
+                if (np > 0) {
+                    SkinnyBwdJob job{};
+                    for (int i = 0; i < np; ++i) job.pairs[i] = prs[i];
+                    job.npairs = np; job.cell = c;
+                    MMQG_TRY(skinny_cell_bwd_plus(job, &look, with_look ? 1 : 0, s));
+                } else {
+                    MMQG_TRY(lstm_cell_bwd(c, s));
+                    if (with_look) MMQG_TRY(skinny_plain_multi(&look, 1, s));
+                }
+                if (l == 0) {   // dctx(t) = dgates_0(t) * W_ih0[:, E:]  (+ layer 0's look-ahead product)
+                    SkinnyPlainJob pj[2] = {};
+                    pj[0].M = B; pj[0].N = C; pj[0].npairs = 1; pj[0].C = g.dctx + (int64_t)t * B * C; pj[0].ldc = C;
+                    pj[0].pairs[0] = SkinnyPair{dg, 4 * H, d.w_ih0cT, 4 * H, 4 * H, 0};
+                    int nj = 1;
+                    if (ahead && t > 0) {
+                        pj[1].M = B; pj[1].N = H; pj[1].npairs = 1; pj[1].C = g.dh_pre; pj[1].ldc = H;
+                        pj[1].pairs[0] = SkinnyPair{dg, 4 * H, d.w_hhT[0], 4 * H, 4 * H, 0};
+                        nj = 2;
+                    }
+                    MMQG_TRY(skinny_plain_multi(pj, nj, s));
                 }
                 continue;
             }

@@ -41,6 +41,7 @@ struct Pair {
 
 struct SkinnyK {
     int M, N;
+    int plain;                     // job of a BWD_CELL launch that is a plain product (C/ldc/beta/bias epilogue)
     Pair p[3];
     int cs1, cs2, chunks;          // first chunk of pair 1 / pair 2, total 16-wide k-chunks
     // PLAIN
@@ -58,6 +59,7 @@ struct SkinnyK {
     float* carry;                                  // [M][H] in: carried gradient of finished rows / dhT; out: carry for t-1
     const float* above; int64_t above_stride_b;    // element-wise gradient from the layer above (masked)
     const float* extra; int64_t extra_stride_b;    // further gradient of h(t), active rows only
+    const float* pre;                              // [M][H] product formed ahead of time, every row
     float* dc; float* dgates;
 };
 
@@ -108,19 +110,21 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
     // Epilogue operands are requested now so their latency hides behind the operand stream.
     const int e_row = (threadIdx.x >> 4) & 15, e_col = threadIdx.x & 15;
     const int e_b = m0 + e_row;
-    float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f, pf4 = 0.f, pf5 = 0.f;
+    // (no arithmetic on the fetched values here: an add would make the wave wait for them before it
+    // may issue its operand loads)
+    float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f, pf4 = 0.f, pf5 = 0.f, pf6 = 0.f;
     if (threadIdx.x < 256 && e_b < a.M) {
         if (MODE == MODE_FWD_CELL) {
             const int gc = (e_col >> 2) * a.H + n0 + (e_col & 3);
             if (a.gates_has_pre) pf0 = a.gates[(int64_t)e_b * 4 * a.H + gc];
-            if (a.bias1) pf0 += a.bias1[gc];
-            if (a.bias2) pf0 += a.bias2[gc];
+            if (a.bias1) pf3 = a.bias1[gc];
+            if (a.bias2) pf4 = a.bias2[gc];
             if ((e_col >> 2) == 0) {
                 const int64_t e = (int64_t)e_b * a.H + n0 + (e_col & 3);
                 pf1 = a.h_prev[e];
                 pf2 = a.c_prev[e];
             }
-        } else if (MODE == MODE_BWD_CELL) {
+        } else if (MODE == MODE_BWD_CELL && !a.plain) {
             const int j = n0 + e_col;
             if (j < a.H) {
                 const int64_t e = (int64_t)e_b * a.H + j;
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
                 pf3 = a.c_prev[e];
                 if (a.above) pf4 = a.above[(int64_t)e_b * a.above_stride_b + j];
                 if (a.extra) pf5 = a.extra[(int64_t)e_b * a.extra_stride_b + j];
+                if (a.pre) pf6 = a.pre[e];
             }
         }
     }
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
     }
     const int b = m0 + row;
 
-    if (MODE == MODE_PLAIN) {
+    if (MODE == MODE_PLAIN || (MODE == MODE_BWD_CELL && a.plain)) {
         const int n = n0 + col;
         if (b < a.M && n < a.N) {
             float* dst = a.C + (int64_t)b * a.ldc + n;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
     if (MODE == MODE_FWD_CELL) {
         const int H = a.H;
         const int g = col >> 2, j = n0 + (col & 3);
-        const float pre = s + pf0;
+        const float pre = s + pf0 + pf3 + pf4;
         __syncthreads();                        // all partial sums consumed: reuse part[0][0] for the tile
         if (tid < 256) part[0][0][row][col] = pre;
         __syncthreads();
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
         const int64_t e = (int64_t)b * H + j;
         float mask = 1.f;
         bool have_mask = false;
-        float dh = s + pf0;
+        float dh = s + pf0 + pf6;
         if (a.p[1].masked || a.p[2].masked || a.p[0].masked) {
             if (a.drop_p > 0.f) { mask = dropout_scale(eff_seed(a.seed, a.seed_off), a.stream_id, (uint64_t)e, a.drop_p); }
             have_mask = true;
@@ -323,17 +328,19 @@ bool pair_ok(const mmqg::SkinnyPair& p) {
 template <int MODE>
 int launch_skinny_batch(const SkinnyBatch& b, int njobs, hipStream_t s, const char* what) {
     int tiles_n = 0, tiles_m = 0, chunks = 0;
+    int64_t wgs = 0;       // workgroups that do work (the grid is the bounding box of the jobs)
     for (int i = 0; i < njobs; ++i) {
         const SkinnyK& k = b.job[i];
-        tiles_n = std::max(tiles_n, MODE == MODE_FWD_CELL ? k.H / 4 : mmqg::ceil_div(k.N, 16));
-        tiles_m = std::max(tiles_m, mmqg::ceil_div(k.M, 16));
+        const int tn = MODE == MODE_FWD_CELL ? k.H / 4 : mmqg::ceil_div(k.N, 16), tm = mmqg::ceil_div(k.M, 16);
+        tiles_n = std::max(tiles_n, tn);
+        tiles_m = std::max(tiles_m, tm);
+        wgs += (int64_t)tn * tm;
         chunks = std::max(chunks, k.chunks);
     }
     dim3 grid(tiles_n, tiles_m, njobs);
     // 8 k-slices per tile once a tile has >= 64 k-chunks, unless that would put more than ~4096 waves
     // in flight (three layer-steps in one launch): beyond that the extra waves only add fixed cost
     static const int ks8_from = [] { const char* e = getenv("MMQG_SKINNY_KS8_FROM"); return e ? atoi(e) : 64; }();
-    const int64_t wgs = (int64_t)tiles_n * tiles_m * njobs;
     if (chunks >= ks8_from && wgs * 8 <= 4096) hipLaunchKernelGGL((skinny_kernel<MODE, 8>), grid, dim3(512), 0, s, b);
     else hipLaunchKernelGGL((skinny_kernel<MODE, 4>), grid, dim3(256), 0, s, b);
     return mmqg::check_launch(what);
@@ -386,6 +393,20 @@ int skinny_plain(int M, int N, const SkinnyPair* pairs, int npairs, const float*
     return launch_skinny<MODE_PLAIN>(k, ceil_div(N, 16), s, "skinny_plain");
 }
 
+static int fill_plain_job(SkinnyK& k, const SkinnyPlainJob& j) {
+    MMQG_REQUIRE(j.M > 0 && j.N > 0 && j.C && j.ldc >= j.N, "skinny_plain: bad arguments");
+    MMQG_TRY(fill_pairs(k, j.pairs, j.npairs, "skinny_plain"));
+    k.M = j.M; k.N = j.N; k.C = j.C; k.ldc = j.ldc; k.beta = j.beta ? 1 : 0; k.bias = j.bias; k.plain = 1;
+    return 0;
+}
+
+int skinny_plain_multi(const SkinnyPlainJob* jobs, int njobs, hipStream_t s) {
+    MMQG_REQUIRE(njobs >= 1 && njobs <= 3, "skinny_plain_multi: 1..3 jobs");
+    SkinnyBatch b{};
+    for (int i = 0; i < njobs; ++i) MMQG_TRY(fill_plain_job(b.job[i], jobs[i]));
+    return launch_skinny_batch<MODE_PLAIN>(b, njobs, s, "skinny_plain");
+}
+
 static int fill_fwd_job(SkinnyK& k, const SkinnyFwdJob& j) {
     const CellFwd& f = j.cell;
     MMQG_REQUIRE(f.B > 0 && f.H > 0 && f.H % 4 == 0 && f.ld_g == 4 * f.H, "skinny_cell_fwd: need H %% 4 == 0 and compact gates");
@@ -408,6 +429,7 @@ static int fill_bwd_job(SkinnyK& k, const SkinnyBwdJob& j) {
     k.lens = f.lens; k.t = f.t; k.drop_p = f.p; k.seed = f.seed; k.stream_id = f.stream_id; k.seed_off = f.seed_off;
     k.gates_act = f.gates_act; k.c_prev = f.c_prev; k.c_new = f.c_new; k.carry = f.dh_rec;
     k.above = f.dh_above; k.above_stride_b = f.above_stride_b; k.extra = f.dh_extra; k.extra_stride_b = f.extra_stride_b;
+    k.pre = f.dh_pre;
     k.dc = f.dc; k.dgates = f.dgates;
     return 0;
 }
@@ -424,6 +446,14 @@ int skinny_cell_bwd_multi(const SkinnyBwdJob* jobs, int njobs, hipStream_t s) {
     SkinnyBatch b{};
     for (int i = 0; i < njobs; ++i) MMQG_TRY(fill_bwd_job(b.job[i], jobs[i]));
     return launch_skinny_batch<MODE_BWD_CELL>(b, njobs, s, "skinny_cell_bwd");
+}
+
+int skinny_cell_bwd_plus(const SkinnyBwdJob& cell, const SkinnyPlainJob* extra, int nextra, hipStream_t s) {
+    MMQG_REQUIRE(nextra >= 0 && nextra <= 2, "skinny_cell_bwd_plus: at most 2 extra products");
+    SkinnyBatch b{};
+    MMQG_TRY(fill_bwd_job(b.job[0], cell));
+    for (int i = 0; i < nextra; ++i) MMQG_TRY(fill_plain_job(b.job[1 + i], extra[i]));
+    return launch_skinny_batch<MODE_BWD_CELL>(b, 1 + nextra, s, "skinny_cell_bwd");
 }
 
 int skinny_cell_fwd(const SkinnyPair* pairs, int npairs, int gates_has_pre, const float* bias1, const float* bias2,

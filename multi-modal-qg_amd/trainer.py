@@ -23,6 +23,7 @@ and therefore sits in two of the reference's three Adam optimizers (train.py:236
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -88,6 +89,8 @@ class BatchedTrainer:
         self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
         self._dec_reduced = False
         self._side = torch.cuda.Stream(device=self.dev)
+        if os.environ.get("MMQG_NO_AHEAD", "0") != "1":      # look-ahead recurrent products in the decoder's backward loop
+            self.g_dec.dh_pre = self.ws["dpre_d"].data_ptr()
         self.reducer = GradReducer(self.flat_g, trainer_buckets(self.segments, self.n_params), self.pg)
         if self.distributed:
             broadcast_parameters(self.flat_p, self.pg)
@@ -178,7 +181,7 @@ class BatchedTrainer:
         # backward
         w["dhtop"] = f(Td, B, H)
         w["dgates_d"], w["dscores"], w["dctx"] = f(L, Td, B, 4 * H), f(Td, B, ldS), f(Td, B, Cw)
-        w["dh_d"], w["dc_d"], w["dxa"] = f(L, B, H), f(L, B, H), f(L, B, H)
+        w["dh_d"], w["dc_d"], w["dxa"], w["dpre_d"] = f(L, B, H), f(L, B, H), f(L, B, H), f(L, B, H)
         w["dxemb_d"] = f(Td, B, E)
         w["dtext"], w["dvideo"] = f(Tc, B, H), f(Tf, B, Hv)
         w["dgates_t"], w["dxl_t"], w["dh_t"], w["dc_t"] = f(L, Tc, B, 4 * H), f(Tc, B, H), f(L, B, H), f(L, B, H)

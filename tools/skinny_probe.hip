@@ -93,18 +93,19 @@ int main() {
         return j;
     };
 
-    struct Case { const char* name; int njobs; bool bwd; int nwg; };
-    const Case cases[] = {{"FWD_CELL 1 job (K=2x512)", 1, false, 128 * 4}, {"FWD_CELL 3 jobs", 3, false, 128 * 4 * 3},
-                          {"BWD_CELL 1 job (K=2x2048)", 1, true, 32 * 4}, {"BWD_CELL 3 jobs", 3, true, 32 * 4 * 3}};
+    struct Case { const char* name; int njobs; bool bwd; int nwg; int layer; };
+    const Case cases[] = {{"FWD_CELL 1 job (K=2x512)", 1, false, 128 * 4, 1}, {"FWD_CELL 3 jobs", 3, false, 128 * 4 * 3, 0},
+                          {"BWD_CELL 1 job (K=2x2048)", 1, true, 32 * 4, 1}, {"BWD_CELL 1 job (K=1x2048)", 1, true, 32 * 4, 2},
+                          {"BWD_CELL 3 jobs", 3, true, 32 * 4 * 3, 0}};
     for (const Case& cs_ : cases) {
         auto enqueue = [&](int t) {
             if (!cs_.bwd) {
                 mmqg::SkinnyFwdJob jobs[3];
-                for (int i = 0; i < cs_.njobs; ++i) jobs[i] = fwd_job(cs_.njobs == 1 ? 1 : i, t);
+                for (int i = 0; i < cs_.njobs; ++i) jobs[i] = fwd_job(cs_.njobs == 1 ? cs_.layer : i, t);
                 if (mmqg::skinny_cell_fwd_multi(jobs, cs_.njobs, s)) exit(3);
             } else {
                 mmqg::SkinnyBwdJob jobs[3];
-                for (int i = 0; i < cs_.njobs; ++i) jobs[i] = bwd_job(cs_.njobs == 1 ? 1 : i, t);
+                for (int i = 0; i < cs_.njobs; ++i) jobs[i] = bwd_job(cs_.njobs == 1 ? cs_.layer : i, t);
                 if (mmqg::skinny_cell_bwd_multi(jobs, cs_.njobs, s)) exit(3);
             }
         };
