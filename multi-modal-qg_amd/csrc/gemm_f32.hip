@@ -24,6 +24,8 @@
 // tile t+1 before the MFMAs of tile t, then written to the other LDS stage (one barrier per tile).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "mmqg_common.h"
 #include "mmqg_kernels.h"
 
@@ -151,7 +153,7 @@ struct TileLoader {
 };
 
 template <int BM, int BN, int BK, bool A_K, bool B_K, bool CHECK>
-__device__ __forceinline__ void gemm_body(const GemmArgs& p, float* smem) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, float* smem, int tile_x, int tile_y, int kslice) {
     using LA = TileLoader<BM, BK, A_K>;
     using LB = TileLoader<BN, BK, B_K>;
     constexpr int WTM = BM / 2, WTN = BN / 2;      // wave tile
@@ -160,7 +162,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, float* smem) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = tile_y * BM, n0 = tile_x * BN;
 
     const int nk1 = (p.K + BK - 1) / BK;
     const int nk2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, float* smem) {
     int kt_begin = 0, kt_end = nk;
     if (p.split_k > 1) {
         const int per = (nk + p.split_k - 1) / p.split_k;
-        kt_begin = blockIdx.z * per;
+        kt_begin = kslice * per;
         kt_end = min(nk, kt_begin + per);
         if (kt_begin >= kt_end) return;
     }
@@ -243,7 +245,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, float* smem) {
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool lead = (p.split_k <= 1) || (blockIdx.z == 0);
+    const bool lead = (p.split_k <= 1) || (kslice == 0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wc * WTN + j * 32 + l31;
@@ -276,8 +278,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LA::LD + LB::LD)];
     // interior tiles of aligned operands (p.fast, decided on the host) skip every bounds check of the loaders
     const bool interior = p.fast && (int)(blockIdx.y + 1) * BM <= p.M && (int)(blockIdx.x + 1) * BN <= p.N;
-    if (interior) gemm_body<BM, BN, BK, A_K, B_K, false>(p, smem);
-    else gemm_body<BM, BN, BK, A_K, B_K, true>(p, smem);
+    if (interior) gemm_body<BM, BN, BK, A_K, B_K, false>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    else gemm_body<BM, BN, BK, A_K, B_K, true>(p, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent products of one layout in ONE launch (weight gradients of a layer stack): grid.z =
+// problem x k-slice, the x/y extent is the largest problem's tile grid, every problem accumulates (beta = 1)
+// so k-slices simply add atomically.
+constexpr int kMaxGroup = 6;
+struct GemmBatch { GemmArgs p[kMaxGroup]; int split; };
+
+template <int BM, int BN, int BK, bool A_K, bool B_K>
+__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmBatch b) {
+    using LA = TileLoader<BM, BK, A_K>;
+    using LB = TileLoader<BN, BK, B_K>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LA::LD + LB::LD)];
+    const int prob = blockIdx.z / b.split, kslice = blockIdx.z % b.split;
+    const GemmArgs& p = b.p[prob];
+    if ((int)blockIdx.y * BM >= p.M || (int)blockIdx.x * BN >= p.N) return;
+    const bool interior = p.fast && (int)(blockIdx.y + 1) * BM <= p.M && (int)(blockIdx.x + 1) * BN <= p.N;
+    if (interior) gemm_body<BM, BN, BK, A_K, B_K, false>(p, smem, blockIdx.x, blockIdx.y, kslice);
+    else gemm_body<BM, BN, BK, A_K, B_K, true>(p, smem, blockIdx.x, blockIdx.y, kslice);
 }
 
 template <int BM, int BN, int BK>
@@ -382,6 +403,51 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
     if (small) return launch<64, 64, 32>(a, a_layout, b_layout, s);
     if (big_bk == 32) return launch<128, 128, 32>(a, a_layout, b_layout, s);
     return launch<128, 128, 16>(a, a_layout, b_layout, s);
+}
+
+int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n, hipStream_t s) {
+    MMQG_REQUIRE(n >= 0 && (n == 0 || probs), "gemm_f32_grouped: bad arguments");
+    static const int no_group = env_int("MMQG_GEMM_NO_GROUP", 0);
+    // one launch pays off for 128x128-tileable accumulating products; anything else goes one by one
+    bool ok = !no_group && n >= 2 && a_layout == MMQG_MN_MAJOR && b_layout == MMQG_MN_MAJOR;
+    for (int i = 0; i < n && ok; ++i)
+        ok = probs[i].beta == 1 && probs[i].M >= 128 && probs[i].N >= 128 && probs[i].K >= 1 && probs[i].A && probs[i].B && probs[i].C;
+    if (!ok) {
+        for (int i = 0; i < n; ++i) {
+            const GemmProblem& q = probs[i];
+            MMQG_TRY(gemm_f32(a_layout, b_layout, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, nullptr, 0, nullptr, 0, 0, nullptr,
+                              nullptr, q.beta, q.C, q.ldc, -1, s));
+        }
+        return 0;
+    }
+    constexpr int BK = 16;
+    for (int i0 = 0; i0 < n; i0 += kMaxGroup) {
+        const int ng = std::min(kMaxGroup, n - i0);
+        GemmBatch b{};
+        int tx = 0, ty = 0, nk_min = 1 << 30;
+        int64_t tiles = 0;
+        for (int i = 0; i < ng; ++i) {
+            const GemmProblem& q = probs[i0 + i];
+            MMQG_REQUIRE(q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N, "gemm_f32_grouped: leading dimension too small");
+            GemmArgs& a = b.p[i];
+            a = GemmArgs{};
+            a.M = q.M; a.N = q.N; a.K = q.K; a.A = q.A; a.lda = q.lda; a.B = q.B; a.ldb = q.ldb; a.C = q.C; a.ldc = q.ldc;
+            a.beta = 1;
+            a.vec_a = can_vec(q.A, q.lda); a.vec_b = can_vec(q.B, q.ldb);
+            a.fast = a.vec_a && a.vec_b;
+            tx = std::max(tx, ceil_div(q.N, 128)); ty = std::max(ty, ceil_div(q.M, 128));
+            tiles += (int64_t)ceil_div(q.N, 128) * ceil_div(q.M, 128);
+            nk_min = std::min(nk_min, ceil_div(q.K, BK));
+        }
+        // k-slices (atomic adds; every problem accumulates anyway): ~3 workgroups per CU, >= 8 k-tiles each
+        int split = 1;
+        while (tiles * split < 640 && nk_min / (split * 2) >= 8 && split < 8) split *= 2;
+        for (int i = 0; i < ng; ++i) b.p[i].split_k = split;
+        b.split = split;
+        hipLaunchKernelGGL((gemm_f32_grouped_kernel<128, 128, BK, false, false>), dim3(tx, ty, ng * split), dim3(256), 0, s, b);
+        MMQG_TRY(check_launch("gemm_f32_grouped"));
+    }
+    return 0;
 }
 
 }  // namespace mmqg

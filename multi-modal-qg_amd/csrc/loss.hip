@@ -101,13 +101,15 @@ __global__ __launch_bounds__(256) void sample_gumbel_kernel(const float* __restr
 
 // out[n] += sum_m X[m][n]; rows split over blockIdx.y, finished with f32 atomics
 __global__ __launch_bounds__(256) void colsum_add_kernel(const float* __restrict__ X, int ld, int M, int N,
-                                                         float* __restrict__ out, int rows_per_block) {
+                                                         float* __restrict__ out, float* __restrict__ out2,
+                                                         int rows_per_block) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
     float acc = 0.f;
     for (int m = m0; m < m1; ++m) acc += X[(int64_t)m * ld + n];
     atomicAdd(out + n, acc);
+    if (out2) atomicAdd(out2 + n, acc);
 }
 
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
@@ -171,13 +173,17 @@ int sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t seed, u
 }
 
 int colsum_add(const float* X, int ld, int M, int N, float* out, hipStream_t s) {
+    return colsum_add2(X, ld, M, N, out, nullptr, s);
+}
+
+int colsum_add2(const float* X, int ld, int M, int N, float* out, float* out2, hipStream_t s) {
     MMQG_REQUIRE(M >= 0 && N >= 0 && ld >= N, "colsum_add: bad shape");
     if (M == 0 || N == 0) return 0;
     MMQG_REQUIRE(X && out, "colsum_add: null pointer");
     int slices = std::min(64, std::max(1, M / 32));
     const int rows_per_block = ceil_div(M, slices);
     slices = ceil_div(M, rows_per_block);
-    hipLaunchKernelGGL(colsum_add_kernel, dim3(ceil_div(N, 256), slices), dim3(256), 0, s, X, ld, M, N, out,
+    hipLaunchKernelGGL(colsum_add_kernel, dim3(ceil_div(N, 256), slices), dim3(256), 0, s, X, ld, M, N, out, out2,
                        rows_per_block);
     return check_launch("colsum_add");
 }

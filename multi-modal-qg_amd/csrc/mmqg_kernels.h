@@ -13,6 +13,9 @@ namespace mmqg {
 int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
              const float* A2, int lda2, const float* B2, int ldb2, int K2, const float* bias, const float* bias2,
              int beta, float* C, int ldc, int split_k, hipStream_t s);
+// independent accumulating products (C += A*B) of one layout in as few launches as possible
+struct GemmProblem { int M, N, K; const float* A; int lda; const float* B; int ldb; float* C; int ldc; int beta; };
+int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n, hipStream_t s);
 
 // ---- lstm_cell.hip --------------------------------------------------------------------
 struct CellFwd {
@@ -94,6 +97,8 @@ int embedding_bwd(const float* dout, int ld, const int64_t* ids, float* dtable, 
 int ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* row_weight, int rows, int V,
                float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, hipStream_t s);
 int colsum_add(const float* X, int ld, int M, int N, float* out, hipStream_t s);
+// out1 += column sums, out2 += the same sums (the two bias gradients of an LSTM layer); out2 may be null
+int colsum_add2(const float* X, int ld, int M, int N, float* out1, float* out2, hipStream_t s);
 int sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t seed, uint64_t stream_id, int64_t* out_ids,
                   hipStream_t s);
 int fill_i64(int64_t* dst, int64_t value, int64_t n, hipStream_t s);

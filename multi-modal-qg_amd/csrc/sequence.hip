@@ -293,26 +293,26 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
             MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, T * B, H, 4 * H, dg_l, 4 * H, d.w_ih[l], H, nullptr, 0, nullptr,
                               0, 0, nullptr, nullptr, 0, g.dxl, H, -1, s));
     }
-    for (int l = L - 1; l >= 0 && do_wgrad; --l) {
-        const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
-        const float* dg_l = g.dgates + (int64_t)l * T * G;
-        const float* X; int ldx, in;
-        if (l == 0) { X = d.x; ldx = d.ldx; in = d.In; }
-        else { X = drop ? d.hdrop + (int64_t)(l - 1) * T * BH : d.hs + (int64_t)(l - 1) * (T + 1) * BH + BH; ldx = H; in = H; }
-        {
-            // recurrence-free products over all T*B rows: layer-0 input gradient, weight / bias gradients
+    if (do_wgrad) {
+        // recurrence-free products over all T*B rows: layer-0 input gradient, then every weight gradient of the
+        // stack as ONE grouped launch (dW += dGates^T X), bias gradients (b_ih and b_hh get the same sums)
+        GemmProblem wg[2 * MMQG_MAX_LAYERS];
+        int nw = 0;
+        for (int l = L - 1; l >= 0; --l) {
+            const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
+            const float* dg_l = g.dgates + (int64_t)l * T * G;
+            const float* X; int ldx, in;
+            if (l == 0) { X = d.x; ldx = d.ldx; in = d.In; }
+            else { X = drop ? d.hdrop + (int64_t)(l - 1) * T * BH : d.hs + (int64_t)(l - 1) * (T + 1) * BH + BH; ldx = H; in = H; }
             if (l == 0 && g.dx)
                 MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, T * B, in, 4 * H, dg_l, 4 * H, d.w_ih[0], in, nullptr, 0,
                                   nullptr, 0, 0, nullptr, nullptr, 0, g.dx, g.lddx, -1, s));
-            if (g.dw_ih[l])
-                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, in, T * B, dg_l, 4 * H, X, ldx, nullptr, 0, nullptr, 0,
-                                  0, nullptr, nullptr, 1, g.dw_ih[l], in, -1, s));
-            if (g.dw_hh[l])
-                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, H, T * B, dg_l, 4 * H, hs_l, H, nullptr, 0, nullptr, 0,
-                                  0, nullptr, nullptr, 1, g.dw_hh[l], H, -1, s));
-            if (g.db_ih[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_ih[l], s));
-            if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_hh[l], s));
+            if (g.dw_ih[l]) wg[nw++] = GemmProblem{4 * H, in, T * B, dg_l, 4 * H, X, ldx, g.dw_ih[l], in, 1};
+            if (g.dw_hh[l]) wg[nw++] = GemmProblem{4 * H, H, T * B, dg_l, 4 * H, hs_l, H, g.dw_hh[l], H, 1};
+            if (g.db_ih[l]) MMQG_TRY(colsum_add2(dg_l, 4 * H, T * B, 4 * H, g.db_ih[l], g.db_hh[l], s));
+            else if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_hh[l], s));
         }
+        MMQG_TRY(gemm_f32_grouped(MMQG_MN_MAJOR, MMQG_MN_MAJOR, wg, nw, s));
     }
     return 0;
 }
@@ -530,12 +530,16 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
     if (fusedb) {
         // gradient of the initial state (the text encoder's final state): carry + dgates_l(0) W_hh_l
         // (+ dscores(0) W_attn_h for the top layer, whose h0 was the query of step 0)
-        for (int l = 0; l < L; ++l) {
-            SkinnyPair prs[2];
-            int np = 0;
-            prs[np++] = SkinnyPair{g.dgates + (int64_t)l * T * G, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
-            if (l == L - 1) prs[np++] = SkinnyPair{g.dscores, ldD, d.w_attn_hT, ldS, ldS, 0};
-            MMQG_TRY(skinny_plain(B, H, prs, np, nullptr, 1, g.dh + l * BH, H, s));
+        for (int l0 = 0; l0 < L; l0 += 3) {     // up to three layers per launch
+            SkinnyPlainJob pj[3] = {};
+            const int nj = std::min(3, L - l0);
+            for (int i = 0; i < nj; ++i) {
+                const int l = l0 + i;
+                pj[i].M = B; pj[i].N = H; pj[i].beta = 1; pj[i].C = g.dh + l * BH; pj[i].ldc = H;
+                pj[i].pairs[pj[i].npairs++] = SkinnyPair{g.dgates + (int64_t)l * T * G, 4 * H, d.w_hhT[l], 4 * H, 4 * H, 0};
+                if (l == L - 1) pj[i].pairs[pj[i].npairs++] = SkinnyPair{g.dscores, ldD, d.w_attn_hT, ldS, ldS, 0};
+            }
+            MMQG_TRY(skinny_plain_multi(pj, nj, s));
         }
     }
     // gradient of the value rows an encoder produced (text rows feed the text encoder's
@@ -557,11 +561,12 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
         MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, R, E, S, g.dscores, ldD, d.w_attn, Q, nullptr, 0, nullptr, 0, 0,
                           nullptr, nullptr, 1, g.dxemb, E, -1, s));
     }
+    // every weight gradient of the decoder (dW += dX^T Y over all T*B rows) as grouped launches
+    GemmProblem wg[2 * MMQG_MAX_LAYERS + 3];
+    int nw = 0;
     if (g.dw_attn) {
-        MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, S, E, R, g.dscores, ldD, d.xemb, E, nullptr, 0, nullptr, 0, 0,
-                          nullptr, nullptr, 1, g.dw_attn, Q, -1, s));
-        MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, S, H, R, g.dscores, ldD, htop_prev, H, nullptr, 0, nullptr, 0, 0,
-                          nullptr, nullptr, 1, g.dw_attn + E, Q, -1, s));
+        wg[nw++] = GemmProblem{S, E, R, g.dscores, ldD, d.xemb, E, g.dw_attn, Q, 1};
+        wg[nw++] = GemmProblem{S, H, R, g.dscores, ldD, htop_prev, H, g.dw_attn + E, Q, 1};
     }
     if (g.db_attn) MMQG_TRY(colsum_add(g.dscores, ldD, R, S, g.db_attn, s));
     for (int l = 0; l < L; ++l) {
@@ -569,22 +574,18 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
         const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
         if (g.dw_ih[l]) {
             if (l == 0) {
-                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, E, R, dg_l, 4 * H, d.xemb, E, nullptr, 0, nullptr, 0,
-                                  0, nullptr, nullptr, 1, g.dw_ih[0], In0, -1, s));
-                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, C, R, dg_l, 4 * H, d.ctx, C, nullptr, 0, nullptr, 0,
-                                  0, nullptr, nullptr, 1, g.dw_ih[0] + E, In0, -1, s));
+                wg[nw++] = GemmProblem{4 * H, E, R, dg_l, 4 * H, d.xemb, E, g.dw_ih[0], In0, 1};
+                wg[nw++] = GemmProblem{4 * H, C, R, dg_l, 4 * H, d.ctx, C, g.dw_ih[0] + E, In0, 1};
             } else {
                 const float* X = drop ? d.hdrop + (int64_t)(l - 1) * T * BH : d.hs + (int64_t)(l - 1) * (T + 1) * BH + BH;
-                MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, H, R, dg_l, 4 * H, X, H, nullptr, 0, nullptr, 0, 0,
-                                  nullptr, nullptr, 1, g.dw_ih[l], H, -1, s));
+                wg[nw++] = GemmProblem{4 * H, H, R, dg_l, 4 * H, X, H, g.dw_ih[l], H, 1};
             }
         }
-        if (g.dw_hh[l])
-            MMQG_TRY(gemm_f32(MMQG_MN_MAJOR, MMQG_MN_MAJOR, 4 * H, H, R, dg_l, 4 * H, hs_l, H, nullptr, 0, nullptr, 0, 0,
-                              nullptr, nullptr, 1, g.dw_hh[l], H, -1, s));
-        if (g.db_ih[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, R, 4 * H, g.db_ih[l], s));
-        if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, R, 4 * H, g.db_hh[l], s));
+        if (g.dw_hh[l]) wg[nw++] = GemmProblem{4 * H, H, R, dg_l, 4 * H, hs_l, H, g.dw_hh[l], H, 1};
+        if (g.db_ih[l]) MMQG_TRY(colsum_add2(dg_l, 4 * H, R, 4 * H, g.db_ih[l], g.db_hh[l], s));
+        else if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, R, 4 * H, g.db_hh[l], s));
     }
+    MMQG_TRY(gemm_f32_grouped(MMQG_MN_MAJOR, MMQG_MN_MAJOR, wg, nw, s));
     return 0;
 }
 
