@@ -81,8 +81,11 @@ __device__ unsigned long long* g_skinny_trace = nullptr;
 #define MMQG_STAMP(slot)
 #endif
 
+// The 4-wave forward variant serves the three-job wavefront launches (1536 workgroups): at <= 85 VGPRs six
+// of its workgroups fit a CU, so the whole launch is resident at once instead of needing a second round
+// (31 -> 25 us per launch).  The 8-wave backward variant is held to 128 VGPRs for two workgroups per CU.
 template <int MODE, int KS>
-__global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
+__global__ __launch_bounds__(KS * 64, (MODE == MODE_FWD_CELL && KS == 4) ? 6 : (MODE == MODE_BWD_CELL && KS == 8) ? 4 : 1) void skinny_kernel(SkinnyBatch batch) {
     __shared__ float part[2][KS][16][17];
     MMQG_STAMP(0)
     const SkinnyK& a = batch.job[blockIdx.z];
@@ -130,10 +133,6 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
                 const int64_t e = (int64_t)e_b * a.H + j;
                 pf0 = a.carry[e];
                 pf1 = a.c_new[e];
-                pf2 = a.dc[e];
-                pf3 = a.c_prev[e];
-                if (a.above) pf4 = a.above[(int64_t)e_b * a.above_stride_b + j];
-                if (a.extra) pf5 = a.extra[(int64_t)e_b * a.extra_stride_b + j];
                 if (a.pre) pf6 = a.pre[e];
             }
         }
@@ -154,7 +153,9 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
         const float* __restrict__ Bp = a.p[pi].B + (int64_t)nb * a.p[pi].ldb;
         const int K = a.p[pi].K;
         const bool masked = (MODE == MODE_BWD_CELL) && a.p[pi].masked;
-        constexpr int U = 8;     // k-chunks in flight per wave: 16 x 16-byte loads, one latency exposure
+        // k-chunks in flight per wave (2*U 16-byte loads per latency exposure); 4 for the 4-wave forward variant,
+        // whose register budget is what lets six workgroups share a CU
+        constexpr int U = (MODE == MODE_FWD_CELL && KS == 4) ? 4 : 8;
         for (int q = lo; q < hi; q += U) {
             float4 av[U], bv[U];
 #pragma unroll
@@ -194,6 +195,16 @@ __global__ __launch_bounds__(KS * 64) void skinny_kernel(SkinnyBatch batch) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (MODE == MODE_BWD_CELL && !a.plain && threadIdx.x < 256 && e_b < a.M && n0 + e_col < a.H) {
+        // the remaining epilogue operands are fetched here, behind the partial-tile exchange: held across the
+        // operand loop they cost the registers of the fourth wave per SIMD (= two 8-wave workgroups per CU).  In
+        // an isolated chain this is slightly slower, inside the two-stream training step it measured +1.2%.
+        const int64_t e = (int64_t)e_b * a.H + n0 + e_col;
+        pf2 = a.dc[e];
+        pf3 = a.c_prev[e];
+        if (a.above) pf4 = a.above[(int64_t)e_b * a.above_stride_b + n0 + e_col];
+        if (a.extra) pf5 = a.extra[(int64_t)e_b * a.extra_stride_b + n0 + e_col];
     }
     // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
