@@ -52,6 +52,20 @@ int mmqg_gemm_f32(int a_layout, int b_layout, int M, int N, int K,
                   const float* bias, const float* bias2, int beta, float* C, int ldc,
                   int split_k, mmqg_stream stream);
 
+/* Several independent products C_i = beta_i*C_i + A_i*B_i of ONE layout pair.  When every product
+ * accumulates (beta = 1), is m-major x n-major (the weight gradients dW += dY^T X of a layer stack:
+ * train.py:177 loss.backward()) and reaches the 128x128 tile, they run as one launch whose K slices
+ * add atomically; otherwise they are issued one by one (same results either way). */
+typedef struct {
+    int32_t M, N, K;
+    const float* A; int32_t lda;
+    const float* B; int32_t ldb;
+    float* C; int32_t ldc;
+    int32_t beta;
+} mmqg_gemm_problem;
+int mmqg_gemm_f32_grouped(int a_layout, int b_layout, const mmqg_gemm_problem* problems, int n,
+                          mmqg_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Embedding lookup and its dense gradient (nn.Embedding shared by encoder.py:96 and
  * decoder.py:75; train.py:25-31).  ids outside [0,V) yield a zero row / are skipped. */

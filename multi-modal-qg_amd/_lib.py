@@ -93,6 +93,11 @@ class DecoderSeqGrad(C.Structure):
                 ("phase", C.c_int32), ("dh_pre", c_f)]
 
 
+class GemmProblem(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("A", c_f), ("lda", C.c_int32), ("B", c_f),
+                ("ldb", C.c_int32), ("C", c_f), ("ldc", C.c_int32), ("beta", C.c_int32)]
+
+
 CNN_MAX_BLOCKS = 4
 
 
@@ -123,6 +128,7 @@ SIGNATURES = {
     "mmqg_last_error": [],
     "mmqg_gemm_f32": [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_i,
                       c_i, c_f],
+    "mmqg_gemm_f32_grouped": [c_i, c_i, C.POINTER(GemmProblem), c_i, c_f],
     "mmqg_embedding_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mmqg_embedding_bwd": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f],
     "mmqg_attn_softmax_context_fwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f],

@@ -41,6 +41,11 @@ int mmqg_gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* 
                     split_k, S(stream));
 }
 
+int mmqg_gemm_f32_grouped(int a_layout, int b_layout, const mmqg_gemm_problem* problems, int n, mmqg_stream stream) {
+    MMQG_REQUIRE(a_layout == MMQG_K_MAJOR || a_layout == MMQG_MN_MAJOR, "gemm_f32_grouped: bad a_layout");
+    MMQG_REQUIRE(b_layout == MMQG_K_MAJOR || b_layout == MMQG_MN_MAJOR, "gemm_f32_grouped: bad b_layout");
+    return gemm_f32_grouped(a_layout, b_layout, problems, n, S(stream));
+}
 int mmqg_embedding_fwd(const float* table, const int64_t* ids, float* out, int n, int V, int E, int ld_out,
                        mmqg_stream stream) {
     return embedding_fwd(table, ids, out, n, V, E, ld_out, S(stream));

@@ -14,7 +14,7 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
              const float* A2, int lda2, const float* B2, int ldb2, int K2, const float* bias, const float* bias2,
              int beta, float* C, int ldc, int split_k, hipStream_t s);
 // independent accumulating products (C += A*B) of one layout in as few launches as possible
-struct GemmProblem { int M, N, K; const float* A; int lda; const float* B; int ldb; float* C; int ldc; int beta; };
+typedef mmqg_gemm_problem GemmProblem;
 int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n, hipStream_t s);
 
 // ---- lstm_cell.hip --------------------------------------------------------------------

@@ -564,3 +564,44 @@ def test_frame_cnn_pool_argmax_ties_pick_first(mm):
     close(got, want.detach(), tol=5e-4, what="features")
     for k in ("conv4.weight", "conv4.bias", "bn4.weight", "bn4.bias"):
         close(vid32[k].grad, leaf[k].grad, tol=5e-4, what=f"d{k}")
+
+
+# ---------------------------------------------------------------------------- grouped GEMM
+@pytest.mark.parametrize("case", [
+    # (a_layout, b_layout, [(M, N, K, beta, ldc_pad)], what)
+    (1, 1, [(256, 128, 2048, 1, 0), (256, 300, 1280, 1, 212), (384, 512, 2048, 1, 0)], "one launch, k-slices add atomically"),
+    (1, 1, [(2048, 512, 80, 1, 0), (2048, 300, 80, 1, 0)], "one launch, no k split (short K)"),
+    (1, 1, [(256, 128, 512, 1, 0), (64, 96, 200, 1, 0)], "a small member: issued one by one"),
+    (1, 1, [(256, 256, 512, 0, 0), (256, 256, 512, 1, 0)], "a member that overwrites: one by one"),
+    (0, 0, [(130, 257, 300, 1, 3), (256, 128, 64, 1, 0)], "k-major operands: one by one"),
+])
+def test_grouped_gemm_against_float64(mm, case):
+    """mmqg_gemm_f32_grouped: every member C_i = beta*C_i + A_i*B_i vs float64, whichever way it is issued."""
+    _lib, ops = mm
+    a_layout, b_layout, members, what = case
+    g = torch.Generator().manual_seed(len(members) * 1000 + members[0][2])
+    probs = (_lib.GemmProblem * len(members))()
+    keep, want = [], []
+    for i, (M, N, K, beta, pad) in enumerate(members):
+        A = torch.randn((M, K) if a_layout == 0 else (K, M), generator=g)
+        B = torch.randn((N, K) if b_layout == 0 else (K, N), generator=g)
+        C0 = torch.randn(M, N + pad, generator=g)
+        A64 = A.double() if a_layout == 0 else A.double().t()
+        B64 = B.double().t() if b_layout == 0 else B.double()
+        ref = (C0[:, :N].double() if beta else 0) + A64 @ B64
+        dA, dB, dC = dev(A), dev(B), dev(C0)
+        keep += [dA, dB, dC]
+        p = probs[i]
+        p.M, p.N, p.K, p.beta = M, N, K, beta
+        p.A, p.lda = dA.data_ptr(), A.shape[1]
+        p.B, p.ldb = dB.data_ptr(), B.shape[1]
+        p.C, p.ldc = dC.data_ptr(), N + pad
+        want.append((dC, ref, C0, N, K))
+    _lib.check(_lib.load().mmqg_gemm_f32_grouped(a_layout, b_layout, probs, len(members), torch.cuda.current_stream().cuda_stream),
+               "gemm_f32_grouped")
+    torch.cuda.synchronize()
+    for dC, ref, C0, N, K in want:
+        scale = max(1.0, float(ref.abs().max()))
+        err = float((dC[:, :N].double().cpu() - ref).abs().max())
+        assert err <= TOL * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+        assert torch.equal(dC[:, N:].cpu(), C0[:, N:]), f"{what}: wrote past N"
