@@ -1,8 +1,8 @@
 """Data parallelism for the batched step: one process per GPU, the global batch sharded by
 question (every recurrence and the per-question BatchNorm statistics stay inside one sample, so
 ranks never exchange activations), ONE exchange per iteration: an all-reduce (sum) of the flat
-fp32 gradient buffer over RCCL/xGMI, issued in two buckets so the first overlaps the rest of
-backward.  The 1/world_size scale is folded into the fused Adam kernel (``grad_scale``).
+fp32 gradient buffer over RCCL/xGMI, issued in buckets (decoder | frame encoder | rest) as their
+gradients become final, so the first two overlap the rest of backward.  The 1/world_size scale is folded into the fused Adam kernel (``grad_scale``).
 
 The reference has no distributed code at all; this module is new.
 """
@@ -46,22 +46,29 @@ class GradReducer:
     def __init__(self, flat_g: torch.Tensor, buckets: Sequence[Tuple[str, int, int]], group=None):
         self.flat_g = flat_g
         self.buckets = {name: (a, b) for name, a, b in buckets}
+        self._done: set = set()
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = exchange_needed(group)
         self._pending: List = []
 
     def reduce(self, name: str) -> None:
-        if not self.active:
+        if not self.active or name not in self.buckets or name in self._done:
             return
+        self._done.add(name)
         a, b = self.buckets[name]
         if b > a:
             self._pending.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def reduce_remaining(self) -> None:
+        for name in self.buckets:
+            self.reduce(name)
 
     def finish(self) -> None:
         for w in self._pending:
             w.wait()
         self._pending.clear()
+        self._done.clear()
 
     @property
     def grad_scale(self) -> float:
@@ -69,10 +76,14 @@ class GradReducer:
 
 
 def trainer_buckets(segments: Dict[str, Tuple[int, int]], n_params: int) -> List[Tuple[str, int, int]]:
-    """Two buckets from the trainer's flat layout (dec | text | vid | emb): the decoder's
-    gradients are final after the decoder backward, everything else (text encoder, frame
-    encoder, shared embedding) only after the encoders' backward."""
+    """Buckets from the trainer's flat layout, in the order their gradients become final during
+    backward: the decoder's after the decoder backward, the frame encoder's after its (short)
+    backward on the side stream, everything else (text encoder, shared embedding) only at the end.
+    Layout dec | vid | text | emb gives three buckets; any other order falls back to dec | rest."""
     d0, d1 = segments["dec"]
+    v0, v1 = segments.get("vid", (d1, d1))
+    if 0 <= v0 - d1 < 4 and v1 > v0 and v1 < n_params:
+        return [("dec", d0, v0), ("vid", v0, v1), ("rest", v1, n_params)]
     return [("dec", d0, d1), ("rest", d1, n_params)]
 
 

@@ -87,7 +87,6 @@ class BatchedTrainer:
         self.use_graph = use_graph and not self.distributed
         self._graph = None
         self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
-        self._dec_reduced = False
         self._side = torch.cuda.Stream(device=self.dev)
         if os.environ.get("MMQG_NO_AHEAD", "0") != "1":      # look-ahead recurrent products in the decoder's backward loop
             self.g_dec.dh_pre = self.ws["dpre_d"].data_ptr()
@@ -103,14 +102,15 @@ class BatchedTrainer:
         groups.append(("dec", [dec.text_attn.bias, dec.audio_attn.bias, dec.vid_attn.bias]))          # stacked b_attn
         for p in dec.lstm.flat() + [dec.out_layer.weight, dec.out_layer.bias]:
             groups.append(("dec", [p]))
-        for p in text.lstm.flat():
-            groups.append(("text", [p]))
         seen = {id(p) for _, ps in groups for p in ps}
         emb = dec.emb_layer.weight
-        for p in vid.parameters():
+        seen.add(id(emb))
+        for p in vid.parameters():          # frame encoder right after the decoder: its gradients are final early
             if id(p) not in seen:
                 groups.append(("vid", [p]))
                 seen.add(id(p))
+        for p in text.lstm.flat():
+            groups.append(("text", [p]))
         groups.append(("emb", [emb]))
         off = 0
         self.segments: Dict[str, Tuple[int, int]] = {}
@@ -458,11 +458,12 @@ class BatchedTrainer:
                 # the decoder bucket (everything but the embedding) is final here: start its all-reduce
                 # from the side stream so it runs beside the text encoder's backward
                 self.reducer.reduce("dec")
-                self._dec_reduced = True
             self.g_vid.phase = 0
             check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s2), "lstm_seq_bwd(frames)")
             if self._cnn_on:
                 check(lib.mmqg_frame_cnn_bwd(C.byref(self.d_cnn), C.byref(self.g_cnn), s2), "frame_cnn_bwd")
+            if self.distributed and not torch.cuda.is_current_stream_capturing():
+                self.reducer.reduce("vid")          # frame encoder gradients are final too
         self.g_dec.phase = 0
         self.g_text.phase = 1
         check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, loop)")
@@ -509,11 +510,8 @@ class BatchedTrainer:
 
     def _allreduce(self):
         if self.distributed:
-            if not self._dec_reduced:
-                self.reducer.reduce("dec")
-            self.reducer.reduce("rest")
+            self.reducer.reduce_remaining()
             self.reducer.finish()
-            self._dec_reduced = False
 
     def forward_backward(self, batch: Optional[dict] = None):
         """zero_grad + forward + loss + backward for the batch already loaded (or ``batch``).

@@ -43,6 +43,17 @@ def _worker_reducer(rank, world, port, q):
     red.finish()
     want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
     ok = torch.equal(flat, want) and torch.equal(mid[400:], torch.arange(n, dtype=torch.float32)[400:] * (rank + 1))
+    # trainer layout dec | vid | text | emb (dec ends 2 floats short of the 4-aligned vid start): three buckets
+    flat3 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    segs3 = {"dec": (0, 398), "vid": (400, 500), "text": (500, 800), "emb": (800, n)}
+    b3 = trainer_buckets(segs3, n)
+    ok = ok and b3 == [("dec", 0, 400), ("vid", 400, 500), ("rest", 500, n)]
+    red3 = GradReducer(flat3, b3)
+    red3.reduce("vid")
+    red3.reduce("vid")                      # a second request for the same bucket is ignored
+    red3.reduce_remaining()
+    red3.finish()
+    ok = ok and torch.equal(flat3, want)
     p = torch.full((10,), float(rank))
     broadcast_parameters(p)
     ok = ok and bool((p == 0).all()) and abs(red.grad_scale - 1.0 / world) < 1e-12
