@@ -296,14 +296,14 @@ def test_batched_trainer_matches_oracle_on_seeded_inputs(mm, dropout, ragged, ma
     _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode)
 
 
-@pytest.mark.parametrize("name", ["config2", "config1"])
-def test_full_size_step_matches_oracle(mm, name):
+@pytest.mark.parametrize("name,B", [("config2", 4), ("config1", 4), ("config4", 2), ("config5", 2)])
+def test_full_size_step_matches_oracle(mm, name, B):
     """BASELINE.json's shapes at their full widths (config2: 2048-wide frame features, V=10k, H=512,
-    3 layers, 283/101 attention, dropout 0.2 live; config1: raw 112x112 frames through the CNN),
-    4 ragged questions so the oracle finishes in seconds: loss, every gradient, weights after Adam."""
+    3 layers, 283/101 attention, dropout 0.2 live; config1: raw 112x112 frames through the CNN;
+    config4: 32 frames, 128 context tokens, 40-token decode; config5: V=50k, H=1024), a few ragged
+    questions so the oracle finishes in seconds: loss, every gradient, weights after Adam."""
     from mmqg_amd.synthetic import WORKLOADS, synthetic_batch
     w = WORKLOADS[name]
-    B = 4
     batch = synthetic_batch(w, seed=11, batch=B, ragged=True)
     # first Adam step = lr*g/(|g|+eps): ill-conditioned where |g| ~ eps, so the tight bound is applied to the
     # elements whose gradient is not tiny (and twice the 1e-4 step size bounds the rest)
@@ -441,6 +441,31 @@ def test_device_decode_matches_reference_greedy_ids_and_validate_loss(mm):
     long = tr.decode(batch, max_len=8)                                               # evaluate.py: stop at <end>
     for b in range(3):
         assert truncate_at_end(long["ids"][b].tolist(), c["end_id"])[:8] == [t for t in z[f"eval/{b}/ids_stop"].tolist() if t != c["end_id"]]
+
+
+def test_full_size_device_decode_ids_match_oracle(mm):
+    """Free-running greedy decode at config 2's full widths (4 ragged questions, 21 tokens): token ids
+    bit-exact against the oracle's validate()/evaluate() loop, stop-at-<end> included."""
+    from mmqg_amd.metrics import truncate_at_end
+    from mmqg_amd.synthetic import WORKLOADS, build_models, synthetic_batch
+    from oracle import mmqg_oracle as O
+    w = WORKLOADS["config2"]
+    B, T = 4, 21
+    batch = synthetic_batch(w, seed=5, batch=B, ragged=True)
+    vid, text, dec = build_models(w, "cuda", seed=4)
+    tr = _trainer(mm, vid, text, dec, batch).eval()
+    sd = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in (dec, text, vid)]
+    cfg = dict(num_layers=w.layers, hidden_dim=w.hidden, text_max_length=w.text_max_length,
+               av_max_length=w.av_max_length, video_hidden_dim=w.video_hidden, start_id=1, end_id=2, mask_mode=0)
+    ob = {k: (v.long() if v.dtype == torch.int32 else v) for k, v in batch.items()}
+    want = O.greedy_decode(sd[0], sd[1], sd[2], ob, cfg, T, stop_at_end=False)
+    got = tr.decode(batch, max_len=T)["ids"].cpu()
+    assert got.tolist() == want.tolist()
+    want_stop = O.greedy_decode(sd[0], sd[1], sd[2], ob, cfg, T, stop_at_end=True)
+    for b in range(B):
+        cut = truncate_at_end(got[b].tolist(), 2)
+        ref = want_stop[b].tolist()
+        assert ref[:len(cut)] == cut
 
 
 def test_device_sampling_follows_the_softmax_distribution(mm):
