@@ -329,6 +329,27 @@ typedef struct {
 int mmqg_frame_cnn_fwd(const mmqg_frame_cnn* d, mmqg_stream stream);
 int mmqg_frame_cnn_bwd(const mmqg_frame_cnn* d, const mmqg_frame_cnn_grad* g, mmqg_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One launch that repacks a question-major batch (what train.py:149-160 builds per question, here for
+ * B questions) into the time-major static inputs of the sequence executors: frames / features
+ * [B][Tf][inner] -> feats [Tf][B][inner] (frames NULL = already in place), audio [B][audio_rows][Da] ->
+ * the audio rows of the fused value tensor with rows t >= n_frames[b] zeroed (train.py:156), context /
+ * target ids [B][T] -> [T][B], decoder inputs ids_d[t] = t ? target[t-1] : start_id (train.py:168,175),
+ * row_w[t][b] = (t < tgt_len[b]) / B, and copies of the three length vectors. */
+typedef struct {
+    int32_t B, Tf, Tc, Td, Da, audio_rows;
+    int64_t frame_inner;
+    const float* frames; const float* audio;
+    const int64_t* context; const int64_t* target;
+    const int32_t* ctx_len; const int32_t* tgt_len; const int32_t* n_frames;
+    int64_t start_id;
+    float* feats;
+    float* audio_out; int64_t audio_stride_b;
+    int64_t* ids_c; int64_t* ids_d; int64_t* target_t; float* row_w;
+    int32_t* ctx_len_out; int32_t* tgt_len_out; int32_t* n_frames_out;
+} mmqg_batch_pack;
+int mmqg_pack_batch(const mmqg_batch_pack* a, mmqg_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,14 @@ class GemmProblem(C.Structure):
                 ("ldb", C.c_int32), ("C", c_f), ("ldc", C.c_int32), ("beta", C.c_int32)]
 
 
+class BatchPack(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Tf", C.c_int32), ("Tc", C.c_int32), ("Td", C.c_int32), ("Da", C.c_int32),
+                ("audio_rows", C.c_int32), ("frame_inner", c_i64), ("frames", c_f), ("audio", c_f), ("context", c_f),
+                ("target", c_f), ("ctx_len", c_f), ("tgt_len", c_f), ("n_frames", c_f), ("start_id", c_i64),
+                ("feats", c_f), ("audio_out", c_f), ("audio_stride_b", c_i64), ("ids_c", c_f), ("ids_d", c_f),
+                ("target_t", c_f), ("row_w", c_f), ("ctx_len_out", c_f), ("tgt_len_out", c_f), ("n_frames_out", c_f)]
+
+
 CNN_MAX_BLOCKS = 4
 
 
@@ -129,6 +137,7 @@ SIGNATURES = {
     "mmqg_gemm_f32": [c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_f, c_f, c_i, c_f, c_i,
                       c_i, c_f],
     "mmqg_gemm_f32_grouped": [c_i, c_i, C.POINTER(GemmProblem), c_i, c_f],
+    "mmqg_pack_batch": [C.POINTER(BatchPack), c_f],
     "mmqg_embedding_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mmqg_embedding_bwd": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f],
     "mmqg_attn_softmax_context_fwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f],

@@ -46,6 +46,10 @@ int mmqg_gemm_f32_grouped(int a_layout, int b_layout, const mmqg_gemm_problem* p
     MMQG_REQUIRE(b_layout == MMQG_K_MAJOR || b_layout == MMQG_MN_MAJOR, "gemm_f32_grouped: bad b_layout");
     return gemm_f32_grouped(a_layout, b_layout, problems, n, S(stream));
 }
+int mmqg_pack_batch(const mmqg_batch_pack* a, mmqg_stream stream) {
+    MMQG_REQUIRE(a, "mmqg_pack_batch: null descriptor");
+    return pack_batch(*a, S(stream));
+}
 int mmqg_embedding_fwd(const float* table, const int64_t* ids, float* out, int n, int V, int E, int ld_out,
                        mmqg_stream stream) {
     return embedding_fwd(table, ids, out, n, V, E, ld_out, S(stream));

@@ -134,6 +134,13 @@ __global__ __launch_bounds__(256) void fill_copy_kernel(float* __restrict__ dst,
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src ? src[i] : 0.f;
 }
 
+// several independent fills / copies in one launch (initial states of a layer stack): blockIdx.y = segment
+__global__ __launch_bounds__(256) void fill_copy_multi_kernel(mmqg::CopyBatch b) {
+    const mmqg::CopySeg& c = b.seg[blockIdx.y];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < c.n; i += stride) c.dst[i] = c.src ? c.src[i] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void fill_i64_kernel(int64_t* __restrict__ dst, int64_t value, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = value;
@@ -209,6 +216,25 @@ int copy_or_zero_f32(float* dst, const float* src, int64_t n, hipStream_t s) {
     const int64_t blocks = std::min<int64_t>(ceil_div64(n, 256), 2048);
     hipLaunchKernelGGL(fill_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, n);
     return check_launch("copy_or_zero_f32");
+}
+
+int copy_or_zero_multi(const CopySeg* segs, int n, hipStream_t s) {
+    MMQG_REQUIRE(n >= 0 && (n == 0 || segs), "copy_or_zero_multi: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += kMaxCopySegs) {
+        CopyBatch b{};
+        const int m = std::min(kMaxCopySegs, n - i0);
+        int64_t longest = 0;
+        for (int i = 0; i < m; ++i) {
+            MMQG_REQUIRE(segs[i0 + i].n >= 0 && (segs[i0 + i].n == 0 || segs[i0 + i].dst), "copy_or_zero_multi: bad segment");
+            b.seg[i] = segs[i0 + i];
+            longest = std::max(longest, segs[i0 + i].n);
+        }
+        if (longest == 0) continue;
+        const int64_t blocks = std::min<int64_t>(ceil_div64(longest, 256), 1024);
+        hipLaunchKernelGGL(fill_copy_multi_kernel, dim3((unsigned)blocks, m), dim3(256), 0, s, b);
+        MMQG_TRY(check_launch("copy_or_zero_multi"));
+    }
+    return 0;
 }
 
 int fill_i64(int64_t* dst, int64_t value, int64_t n, hipStream_t s) {

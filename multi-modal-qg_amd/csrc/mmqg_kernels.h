@@ -104,6 +104,11 @@ int sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t seed, u
 int fill_i64(int64_t* dst, int64_t value, int64_t n, hipStream_t s);
 int reduce_sum(const float* x, int n, float* out, hipStream_t s);
 int copy_or_zero_f32(float* dst, const float* src, int64_t n, hipStream_t s);
+constexpr int kMaxCopySegs = 16;
+struct CopySeg { float* dst; const float* src; int64_t n; };
+struct CopyBatch { CopySeg seg[kMaxCopySegs]; };
+// dst_i[0:n_i] = src_i ? src_i[0:n_i] : 0 for every segment, one launch per 16 segments
+int copy_or_zero_multi(const CopySeg* segs, int n, hipStream_t s);
 int axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s);
 int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int rows, int cols,
                      hipStream_t s);
@@ -111,6 +116,9 @@ int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t s
 // ---- cnn.hip --------------------------------------------------------------------------
 int frame_cnn_fwd(const mmqg_frame_cnn& d, hipStream_t s);
 int frame_cnn_bwd(const mmqg_frame_cnn& d, const mmqg_frame_cnn_grad& g, hipStream_t s);
+
+// ---- batch.hip ----
+int pack_batch(const mmqg_batch_pack& a, hipStream_t s);
 
 // ---- adam.hip -------------------------------------------------------------------------
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps,

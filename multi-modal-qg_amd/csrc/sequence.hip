@@ -62,10 +62,12 @@ static int lstm_seq_fwd_wavefront(const mmqg_lstm_seq& d, hipStream_t s) {
     const int T = d.T, B = d.B, H = d.H, L = d.L;
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
     const bool drop = lstm_drop(d);
+    CopySeg init[2 * MMQG_MAX_LAYERS];      // initial states of the whole stack: one launch
     for (int l = 0; l < L; ++l) {
-        MMQG_TRY(copy_or_zero(d.hs + (int64_t)l * (T + 1) * BH, d.h0 ? d.h0 + l * BH : nullptr, (size_t)BH, s));
-        MMQG_TRY(copy_or_zero(d.cs + (int64_t)l * (T + 1) * BH, d.c0 ? d.c0 + l * BH : nullptr, (size_t)BH, s));
+        init[2 * l] = CopySeg{d.hs + (int64_t)l * (T + 1) * BH, d.h0 ? d.h0 + l * BH : nullptr, BH};
+        init[2 * l + 1] = CopySeg{d.cs + (int64_t)l * (T + 1) * BH, d.c0 ? d.c0 + l * BH : nullptr, BH};
     }
+    MMQG_TRY(copy_or_zero_multi(init, 2 * L, s));
     // layer 0: every input product at once
     MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, T * B, 4 * H, d.In, d.x, d.ldx, d.w_ih[0], d.In, nullptr, 0, nullptr, 0, 0,
                       d.b_ih[0], d.b_hh[0], 0, d.gates, 4 * H, -1, s));
@@ -174,10 +176,12 @@ static int lstm_seq_bwd_wavefront(const mmqg_lstm_seq& d, const mmqg_lstm_seq_gr
     const int T = d.T, B = d.B, H = d.H, L = d.L;
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
     const bool drop = lstm_drop(d);
+    CopySeg init[2 * MMQG_MAX_LAYERS];
     for (int l = 0; l < L; ++l) {
-        MMQG_TRY(copy_or_zero(g.dh + l * BH, g.dhT ? g.dhT + l * BH : nullptr, (size_t)BH, s));
-        MMQG_TRY(copy_or_zero(g.dc + l * BH, g.dcT ? g.dcT + l * BH : nullptr, (size_t)BH, s));
+        init[2 * l] = CopySeg{g.dh + l * BH, g.dhT ? g.dhT + l * BH : nullptr, BH};
+        init[2 * l + 1] = CopySeg{g.dc + l * BH, g.dcT ? g.dcT + l * BH : nullptr, BH};
     }
+    MMQG_TRY(copy_or_zero_multi(init, 2 * L, s));
     for (int diag = 0; diag < T + L - 1; ++diag) {
         SkinnyBwdJob jobs[3];
         int nj = 0;
@@ -344,10 +348,12 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
     const bool drop = d.training && d.dropout_p > 0.f && L > 1;
     MMQG_REQUIRE(d.phase >= 0 && d.phase <= 2, "decoder_seq_fwd: phase must be 0, 1 or 2");
     if (d.phase != 1) {
+        CopySeg init[2 * MMQG_MAX_LAYERS];
         for (int l = 0; l < L; ++l) {
-            MMQG_TRY(copy_or_zero(d.hs + (int64_t)l * (T + 1) * BH, d.h0 + l * BH, (size_t)BH, s));
-            MMQG_TRY(copy_or_zero(d.cs + (int64_t)l * (T + 1) * BH, d.c0 + l * BH, (size_t)BH, s));
+            init[2 * l] = CopySeg{d.hs + (int64_t)l * (T + 1) * BH, d.h0 + l * BH, BH};
+            init[2 * l + 1] = CopySeg{d.cs + (int64_t)l * (T + 1) * BH, d.c0 + l * BH, BH};
         }
+        MMQG_TRY(copy_or_zero_multi(init, 2 * L, s));
     }
     if (T == 0) return 0;
     if (d.phase != 2) {
@@ -427,8 +433,10 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
     MMQG_REQUIRE(g.phase >= 0 && g.phase <= 2, "decoder_seq_bwd: phase must be 0, 1 or 2");
     const bool do_loop = g.phase != 2, do_wgrad = g.phase != 1;
     if (do_loop) {
-    MMQG_TRY(copy_or_zero(g.dh, nullptr, (size_t)L * BH, s));
-    MMQG_TRY(copy_or_zero(g.dc, nullptr, (size_t)L * BH, s));
+    {
+        const CopySeg z[2] = {CopySeg{g.dh, nullptr, (int64_t)L * BH}, CopySeg{g.dc, nullptr, (int64_t)L * BH}};
+        MMQG_TRY(copy_or_zero_multi(z, 2, s));
+    }
     // fused backward: possible when k-major (transposed) copies of every recurrent weight are given
     bool fusedb = !g_no_fuse() && d.w_ih0cT && d.w_attn_hT && (ldS % 4 == 0) && (ldD % 4 == 0);
     for (int l = 0; l < L && fusedb; ++l) {

@@ -354,7 +354,7 @@ class BatchedTrainer:
         (B,Tf,C,H,W) raw frames (already in the reference's viewed layout); ``audio`` (B,Tf,Da);
         ``context`` (B,Tc) ids; ``target`` (B,Td) ids; ``ctx_len``/``tgt_len``/``n_frames`` (B,).
         Raw frames switch the HIP frame CNN on for the following forward / backward."""
-        w, B = self.ws, self.B
+        w, B, dev = self.ws, self.B, self.dev
         frames = batch["frames"]
         self._cnn_on = frames.dim() == 5
         if self._cnn_on:
@@ -362,26 +362,31 @@ class BatchedTrainer:
             if self._bn_buffers_moved():          # load_state_dict keeps storage; .to()/re-assignment does not
                 self._cnn_shape = None
                 self._ensure_cnn(tuple(frames.shape[2:]))
-            w["raw"].copy_(frames.to(self.dev).transpose(0, 1))
-        else:
-            w["feats"].copy_(frames.to(self.dev).transpose(0, 1))
-        nf = batch["n_frames"].to(self.dev)
-        w["n_frames"].copy_(nf)
-        w["ctx_len"].copy_(batch["ctx_len"].to(self.dev))
-        w["tgt_len"].copy_(batch["tgt_len"].to(self.dev))
-        ctx = batch["context"].to(self.dev)
-        tgt = batch["target"].to(self.dev)
-        w["ids_c"].copy_(ctx.t())
-        w["target"].copy_(tgt.t())
-        w["ids_d"][0].fill_(self.start_id)                       # train.py:168
-        w["ids_d"][1:].copy_(tgt.t()[:-1])                       # teacher forcing, train.py:175
-        steps = torch.arange(self.Td, device=self.dev).view(-1, 1)
-        w["row_w"].copy_((steps < w["tgt_len"].view(1, -1)).to(torch.float32) / B)
-        # audio features: rows past n_frames must be zero (train.py:156 pads with zeros)
-        audio = batch["audio"].to(self.dev)
-        va = w["values"][:, self.off_audio:self.off_video].view(B, self.Lav, self.Da)
-        keep = (torch.arange(audio.shape[1], device=self.dev).view(1, -1) < nf.view(-1, 1)).unsqueeze(-1)
-        va[:, :audio.shape[1]].copy_(audio * keep)
+
+        def on_dev(t, dtype):
+            t = t.to(device=dev, dtype=dtype)
+            return t if t.is_contiguous() else t.contiguous()
+
+        frames = on_dev(frames, torch.float32)
+        audio = on_dev(batch["audio"], torch.float32)
+        ctx, tgt = on_dev(batch["context"], torch.int64), on_dev(batch["target"], torch.int64)
+        lens = [on_dev(batch[k], torch.int32) for k in ("ctx_len", "tgt_len", "n_frames")]
+        if frames.shape[:2] != (B, self.Tf) or ctx.shape != (B, self.Tc) or tgt.shape != (B, self.Td) or audio.shape[0] != B \
+                or audio.shape[1] > self.Lav or audio.shape[2] != self.Da or any(t.shape != (B,) for t in lens):
+            raise ValueError("batch does not match the trainer's (batch_size, n_frames, ctx_len, tgt_len) extents")
+        if not self._cnn_on and frames.shape[2] != self.Fin:
+            raise ValueError(f"frame features are {frames.shape[2]} wide, the frame LSTM expects {self.Fin}")
+        # ONE kernel repacks everything into the static time-major inputs (csrc/batch.hip)
+        p = _lib.BatchPack(B=B, Tf=self.Tf, Tc=self.Tc, Td=self.Td, Da=self.Da, audio_rows=audio.shape[1],
+                           frame_inner=frames[0, 0].numel(), frames=frames.data_ptr(), audio=audio.data_ptr(),
+                           context=ctx.data_ptr(), target=tgt.data_ptr(), ctx_len=lens[0].data_ptr(),
+                           tgt_len=lens[1].data_ptr(), n_frames=lens[2].data_ptr(), start_id=self.start_id,
+                           feats=(w["raw"] if self._cnn_on else w["feats"]).data_ptr(),
+                           audio_out=w["values"].data_ptr() + 4 * self.off_audio, audio_stride_b=self.val_stride,
+                           ids_c=w["ids_c"].data_ptr(), ids_d=w["ids_d"].data_ptr(), target_t=w["target"].data_ptr(),
+                           row_w=w["row_w"].data_ptr(), ctx_len_out=w["ctx_len"].data_ptr(),
+                           tgt_len_out=w["tgt_len"].data_ptr(), n_frames_out=w["n_frames"].data_ptr())
+        check(_lib.load().mmqg_pack_batch(C.byref(p), ops._stream()), "pack_batch")
 
     # ------------------------------------------------------------------------ one step
     # Two HIP streams: the recurrent time loops are latency-bound chains of small launches, the

@@ -605,3 +605,46 @@ def test_grouped_gemm_against_float64(mm, case):
         err = float((dC[:, :N].double().cpu() - ref).abs().max())
         assert err <= TOL * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
         assert torch.equal(dC[:, N:].cpu(), C0[:, N:]), f"{what}: wrote past N"
+
+
+# ------------------------------------------------------------------------------ batch packing
+@pytest.mark.parametrize("B,Tf,Tc,Td,inner,Da,Ta", [(5, 4, 7, 6, 40, 12, 4), (3, 3, 5, 4, 3 * 6 * 6, 8, 2), (1, 1, 1, 1, 1, 1, 1)])
+def test_pack_batch_bit_exact(mm, B, Tf, Tc, Td, inner, Da, Ta):
+    """mmqg_pack_batch: question-major batch -> time-major static inputs, teacher-forcing ids, loss weights,
+    audio rows zeroed past n_frames (train.py:149-160,168,175).  Pure data movement: bit-exact."""
+    _lib, ops = mm
+    g = torch.Generator().manual_seed(B * 100 + Tf)
+    frames = torch.randn(B, Tf, inner, generator=g)
+    audio = torch.randn(B, Ta, Da, generator=g)
+    ctx = torch.randint(0, 50, (B, Tc), generator=g)
+    tgt = torch.randint(0, 50, (B, Td), generator=g)
+    ctx_len = torch.randint(1, Tc + 1, (B,), generator=g, dtype=torch.int32)
+    tgt_len = torch.randint(1, Td + 1, (B,), generator=g, dtype=torch.int32)
+    n_frames = torch.randint(0, Tf + 1, (B,), generator=g, dtype=torch.int32)
+    stride_b, off = 5 * Da + 7, 3                                   # audio rows live inside a larger per-question block
+    d = {k: dev(v) for k, v in dict(frames=frames, audio=audio, ctx=ctx, tgt=tgt, ctx_len=ctx_len, tgt_len=tgt_len,
+                                    n_frames=n_frames).items()}
+    out = dict(feats=torch.full((Tf, B, inner), 9.0), vals=torch.full((B, stride_b), 9.0), ids_c=torch.full((Tc, B), -1),
+               ids_d=torch.full((Td, B), -1), target=torch.full((Td, B), -1), row_w=torch.full((Td, B), 9.0),
+               cl=torch.zeros(B, dtype=torch.int32), tl=torch.zeros(B, dtype=torch.int32), nf=torch.zeros(B, dtype=torch.int32))
+    o = {k: dev(v) for k, v in out.items()}
+    p = _lib.BatchPack(B=B, Tf=Tf, Tc=Tc, Td=Td, Da=Da, audio_rows=Ta, frame_inner=inner, frames=d["frames"].data_ptr(),
+                       audio=d["audio"].data_ptr(), context=d["ctx"].data_ptr(), target=d["tgt"].data_ptr(),
+                       ctx_len=d["ctx_len"].data_ptr(), tgt_len=d["tgt_len"].data_ptr(), n_frames=d["n_frames"].data_ptr(),
+                       start_id=1, feats=o["feats"].data_ptr(), audio_out=o["vals"].data_ptr() + 4 * off,
+                       audio_stride_b=stride_b, ids_c=o["ids_c"].data_ptr(), ids_d=o["ids_d"].data_ptr(),
+                       target_t=o["target"].data_ptr(), row_w=o["row_w"].data_ptr(), ctx_len_out=o["cl"].data_ptr(),
+                       tgt_len_out=o["tl"].data_ptr(), n_frames_out=o["nf"].data_ptr())
+    _lib.check(_lib.load().mmqg_pack_batch(C.byref(p), torch.cuda.current_stream().cuda_stream), "pack_batch")
+    torch.cuda.synchronize()
+    assert torch.equal(o["feats"].cpu(), frames.transpose(0, 1).contiguous())
+    keep = (torch.arange(Ta).view(1, -1) < n_frames.view(-1, 1)).unsqueeze(-1)
+    vals = o["vals"].cpu()
+    assert torch.equal(vals[:, off:off + Ta * Da].view(B, Ta, Da), audio * keep)
+    assert bool((vals[:, :off] == 9.0).all()) and bool((vals[:, off + Ta * Da:] == 9.0).all())      # nothing else touched
+    assert torch.equal(o["ids_c"].cpu(), ctx.t()) and torch.equal(o["target"].cpu(), tgt.t())
+    want_d = torch.cat([torch.ones(1, B, dtype=torch.long), tgt.t()[:-1]], 0)
+    assert torch.equal(o["ids_d"].cpu(), want_d)
+    want_w = (torch.arange(Td).view(-1, 1) < tgt_len.view(1, -1)).float() / B
+    assert torch.equal(o["row_w"].cpu(), want_w)
+    assert torch.equal(o["cl"].cpu(), ctx_len) and torch.equal(o["tl"].cpu(), tgt_len) and torch.equal(o["nf"].cpu(), n_frames)

@@ -46,6 +46,8 @@ def test_ctypes_structs_match_the_c_layout(lib_mod, tmp_path):
               "mmqg_decoder_decode": ("DecoderDecode", ["values", "emb_table", "b_hh", "w_out", "start_id", "seed", "target",
                                                         "ids", "ld_attn", "xemb", "hs", "logits", "keep_logits"]),
               "mmqg_gemm_problem": ("GemmProblem", ["M", "K", "A", "lda", "B", "C", "ldc", "beta"]),
+              "mmqg_batch_pack": ("BatchPack", ["B", "audio_rows", "frame_inner", "frames", "n_frames", "start_id", "feats",
+                                                "audio_stride_b", "row_w", "n_frames_out"]),
               "mmqg_cnn_block": ("CnnBlock", ["cout", "pool", "w", "running_var", "argmax", "stats", "shift"]),
               "mmqg_frame_cnn": ("FrameCnn", ["B", "training", "time_major", "eps", "momentum", "frames", "n_frames", "block"]),
               "mmqg_frame_cnn_grad": ("FrameCnnGrad", ["dfeat", "dz", "dw", "dbias", "dgamma", "dbeta"])}
