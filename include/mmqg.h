@@ -228,6 +228,8 @@ typedef struct {
     float* hdrop;                                   /* [L-1][T][B][H] or NULL */
     int32_t phase;                                  /* 0 = everything; 1 = hoisted products only (need only
                                                        xemb); 2 = state init + time loop (after phase 1) */
+    int64_t h0_stride_l;                            /* elements between the layers of h0 / c0; 0 = B*H.  Lets h0/c0
+                                                       point at the final slot of an encoder's hs/cs (train.py:169) */
 } mmqg_decoder_seq;
 
 typedef struct {

@@ -67,7 +67,8 @@ class DecoderSeq(C.Structure):
                 ("dropout_p", c_fl), ("training", C.c_int32), ("seed", c_u64), ("stream_base", c_u64),
                 ("seed_offset", c_f),
                 ("scores", c_f), ("attn", c_f), ("ld_attn", C.c_int32),
-                ("ctx", c_f), ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f), ("phase", C.c_int32)]
+                ("ctx", c_f), ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f), ("phase", C.c_int32),
+                ("h0_stride_l", c_i64)]
 
 
 class DecoderDecode(C.Structure):

@@ -325,6 +325,12 @@ __global__ __launch_bounds__(256) void zero_block_kernel(float* C, int M, int N,
     C[(i / N) * ldc + (i % N)] = 0.f;
 }
 
+// compact, 16-byte aligned block: four floats per thread, grid-stride
+__global__ __launch_bounds__(256) void zero_flat4_kernel(float4* C, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) C[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 inline int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -394,6 +400,11 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
         if (memset_api && ldc == N) {
             hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s);
             MMQG_REQUIRE(e == hipSuccess, "gemm_f32: memset failed: %s", hipGetErrorString(e));
+        } else if (ldc == N && ((int64_t)M * N) % 4 == 0 && aligned16(C)) {
+            const int64_t n4 = (int64_t)M * N / 4;
+            hipLaunchKernelGGL(zero_flat4_kernel, dim3((unsigned)std::min<int64_t>(mmqg::ceil_div64(n4, 256), 2048)), dim3(256), 0, s,
+                               reinterpret_cast<float4*>(C), n4);
+            MMQG_TRY(mmqg::check_launch("gemm_f32 zero"));
         } else {
             hipLaunchKernelGGL(zero_block_kernel, dim3((unsigned)mmqg::ceil_div64((int64_t)M * N, 256)), dim3(256), 0, s,
                                C, M, N, ldc);

@@ -350,8 +350,9 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
     if (d.phase != 1) {
         CopySeg init[2 * MMQG_MAX_LAYERS];
         for (int l = 0; l < L; ++l) {
-            init[2 * l] = CopySeg{d.hs + (int64_t)l * (T + 1) * BH, d.h0 + l * BH, BH};
-            init[2 * l + 1] = CopySeg{d.cs + (int64_t)l * (T + 1) * BH, d.c0 + l * BH, BH};
+            const int64_t hstr = d.h0_stride_l ? d.h0_stride_l : BH;
+            init[2 * l] = CopySeg{d.hs + (int64_t)l * (T + 1) * BH, d.h0 + l * hstr, BH};
+            init[2 * l + 1] = CopySeg{d.cs + (int64_t)l * (T + 1) * BH, d.c0 + l * hstr, BH};
         }
         MMQG_TRY(copy_or_zero_multi(init, 2 * L, s));
     }

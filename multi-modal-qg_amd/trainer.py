@@ -258,7 +258,11 @@ class BatchedTrainer:
         dd.gates, dd.hs, dd.cs, dd.hdrop = (w[k].data_ptr() for k in ("gates_d", "hs_d", "cs_d", "hdrop_d"))
         # the encoder's final (h,c) for every layer, gathered into [L,B,H] (train.py:169)
         w["h0_d"], w["c0_d"] = torch.zeros(L, B, H, device=self.dev), torch.zeros(L, B, H, device=self.dev)
-        dd.h0, dd.c0 = w["h0_d"].data_ptr(), w["c0_d"].data_ptr()
+        # training reads the initial state straight from the text encoder's final slot (no gather copy);
+        # h0_d / c0_d remain the inputs of the free-running decode
+        slot = 4 * self.Tc * B * H
+        dd.h0, dd.c0 = w["hs_t"].data_ptr() + slot, w["cs_t"].data_ptr() + slot
+        dd.h0_stride_l = (self.Tc + 1) * B * H
         gd.dhtop, gd.dgates = w["dhtop"].data_ptr(), w["dgates_d"].data_ptr()
         gd.dscores, gd.ld_ds, gd.dctx = w["dscores"].data_ptr(), self.ldS, w["dctx"].data_ptr()
         gd.dh, gd.dc, gd.dxa, gd.dxemb = (w[k].data_ptr() for k in ("dh_d", "dc_d", "dxa", "dxemb_d"))
@@ -424,8 +428,6 @@ class BatchedTrainer:
         s = ops._stream()
         ops.embedding_fwd(emb, w["ids_c"], w["xemb_c"].view(-1, self.E))
         check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_text), s), "lstm_seq_fwd(text)")
-        w["h0_d"].copy_(w["hs_t"][:, self.Tc])
-        w["c0_d"].copy_(w["cs_t"][:, self.Tc])
         self._join()
         self.d_dec.phase = 2
         check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd(loop)")
@@ -442,12 +444,12 @@ class BatchedTrainer:
         logits = w["logits"]
         check(lib.mmqg_ce_fwd_bwd(logits.data_ptr(), V, w["target"].data_ptr(), w["row_w"].data_ptr(), R, V,
                                   w["loss_rows"].data_ptr(), w["argmax"].data_ptr(), logits.data_ptr(), V, s), "ce_fwd_bwd")
-        check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), s), "reduce_sum")
         out = self.dec.out_layer
         htop = w["hs_d"][L - 1, 1:].reshape(R, H)
         demb = self.dec.emb_layer.weight.grad
         # vocabulary projection backward (logits now holds dlogits): weight gradient on the side stream
-        with self._fork():
+        with self._fork():           # the loss scalar is off the dependent chain too
+            check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), ops._stream()), "reduce_sum")
             ops.gemm(MN_MAJOR, MN_MAJOR, V, H, R, logits, V, htop, H, out.weight.grad, H, beta=1)
             ops.colsum_add(logits, out.bias.grad)
         ops.gemm(K_MAJOR, MN_MAJOR, R, H, V, logits, V, out.weight, H, w["dhtop"], H)
