@@ -88,6 +88,7 @@ class BatchedTrainer:
         self._graph = None
         self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
         self._side = torch.cuda.Stream(device=self.dev)
+        self.chain_first = os.environ.get("MMQG_SIDE_FIRST", "0") != "1"
         if os.environ.get("MMQG_NO_AHEAD", "0") != "1":      # look-ahead recurrent products in the decoder's backward loop
             self.g_dec.dh_pre = self.ws["dpre_d"].data_ptr()
         self.reducer = GradReducer(self.flat_g, trainer_buckets(self.segments, self.n_params), self.pg)
@@ -406,6 +407,19 @@ class BatchedTrainer:
     def _join(self):
         torch.cuda.current_stream().wait_stream(self._side)
 
+    # Issue order matters as much as the dependency graph: whoever is enqueued first runs first (host
+    # enqueue in eager mode, node order in a captured graph).  So at every fork the kernels of the
+    # dependent chain are issued BEFORE the side branch: the fork point is marked with an event, the
+    # chain is enqueued, and only then the side stream waits for the mark and receives its work.
+    def _mark(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def _fork_from(self, ev):
+        self._side.wait_event(ev)
+        return torch.cuda.stream(self._side)
+
     def _forward(self, training: bool):
         lib, w = _lib.load(), self.ws
         L, B, H, V = self.L, self.B, self.H, self.V
@@ -414,7 +428,8 @@ class BatchedTrainer:
         self.d_text.dropout_p = self.drop_text if training else 0.0
         self.d_dec.dropout_p = self.drop_dec if training else 0.0
         emb = self.dec.emb_layer.weight
-        with self._fork():
+
+        def side_branch():
             s = ops._stream()
             if self._cnn_on:
                 self.d_cnn.training = int(training)
@@ -425,9 +440,22 @@ class BatchedTrainer:
             check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd(hoists)")
             if training:
                 self._refresh_transposes()
+
+        def chain():
+            s = ops._stream()
+            ops.embedding_fwd(emb, w["ids_c"], w["xemb_c"].view(-1, self.E))
+            check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_text), s), "lstm_seq_fwd(text)")
+
+        if self.chain_first:
+            mark = self._mark()
+            chain()
+            with self._fork_from(mark):
+                side_branch()
+        else:
+            with self._fork():
+                side_branch()
+            chain()
         s = ops._stream()
-        ops.embedding_fwd(emb, w["ids_c"], w["xemb_c"].view(-1, self.E))
-        check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_text), s), "lstm_seq_fwd(text)")
         self._join()
         self.d_dec.phase = 2
         check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd(loop)")
@@ -448,18 +476,32 @@ class BatchedTrainer:
         htop = w["hs_d"][L - 1, 1:].reshape(R, H)
         demb = self.dec.emb_layer.weight.grad
         # vocabulary projection backward (logits now holds dlogits): weight gradient on the side stream
-        with self._fork():           # the loss scalar is off the dependent chain too
+        def vocab_side():            # weight gradient of the projection; the loss scalar is off the chain too
             check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), ops._stream()), "reduce_sum")
             ops.gemm(MN_MAJOR, MN_MAJOR, V, H, R, logits, V, htop, H, out.weight.grad, H, beta=1)
             ops.colsum_add(logits, out.bias.grad)
-        ops.gemm(K_MAJOR, MN_MAJOR, R, H, V, logits, V, out.weight, H, w["dhtop"], H)
-        self.g_dec.phase = 1
-        check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s), "decoder_seq_bwd(loop)")
+
+        def vocab_chain():
+            ops.gemm(K_MAJOR, MN_MAJOR, R, H, V, logits, V, out.weight, H, w["dhtop"], H)
+            self.g_dec.phase = 1
+            check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s), "decoder_seq_bwd(loop)")
+
+        if self.chain_first:
+            mark = self._mark()
+            vocab_chain()
+            with self._fork_from(mark):
+                vocab_side()
+        else:
+            with self._fork():
+                vocab_side()
+            vocab_chain()
         self._join()
-        with self._fork():
+
+        def enc_side():              # decoder weight gradients, frame encoder backward
             s2 = ops._stream()
             self.g_dec.phase = 2
             check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s2), "decoder_seq_bwd(wgrad)")
+            self.g_dec.phase = 0
             ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
             if self.distributed and not torch.cuda.is_current_stream_capturing():
                 # the decoder bucket (everything but the embedding) is final here: start its all-reduce
@@ -471,13 +513,24 @@ class BatchedTrainer:
                 check(lib.mmqg_frame_cnn_bwd(C.byref(self.d_cnn), C.byref(self.g_cnn), s2), "frame_cnn_bwd")
             if self.distributed and not torch.cuda.is_current_stream_capturing():
                 self.reducer.reduce("vid")          # frame encoder gradients are final too
-        self.g_dec.phase = 0
-        self.g_text.phase = 1
-        check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, loop)")
-        self.g_text.phase = 2
-        check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, wgrad)")
-        self.g_text.phase = 0
-        ops.embedding_bwd(w["dxemb_c"].view(-1, E), w["ids_c"], demb)
+
+        def enc_chain():             # text encoder backward: the rest of the dependent chain
+            self.g_text.phase = 1
+            check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, loop)")
+            self.g_text.phase = 2
+            check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, wgrad)")
+            self.g_text.phase = 0
+            ops.embedding_bwd(w["dxemb_c"].view(-1, E), w["ids_c"], demb)
+
+        if self.chain_first:
+            mark = self._mark()
+            enc_chain()
+            with self._fork_from(mark):
+                enc_side()
+        else:
+            with self._fork():
+                enc_side()
+            enc_chain()
         self._join()
         if self.grad_hook:
             self.grad_hook(self, "all")
