@@ -112,6 +112,32 @@ __global__ __launch_bounds__(256) void colsum_add_kernel(const float* __restrict
     if (out2) atomicAdd(out2 + n, acc);
 }
 
+// aligned case: a workgroup covers 256 columns x rows_per_block rows as 64 float4 column lanes x 4 row lanes,
+// the row lanes are combined through LDS, one atomic per column and output
+__global__ __launch_bounds__(256) void colsum_add_vec4_kernel(const float* __restrict__ X, int ld, int M, int N,
+                                                              float* __restrict__ out, float* __restrict__ out2,
+                                                              int rows_per_block) {
+    __shared__ float4 part[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + 4 * cl;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) {
+        for (int m = m0 + rl; m < m1; m += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(X + (int64_t)m * ld + n);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    part[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        const float4 a = part[0][cl], b = part[1][cl], c = part[2][cl], d = part[3][cl];
+        const float s0 = a.x + b.x + c.x + d.x, s1 = a.y + b.y + c.y + d.y, s2 = a.z + b.z + c.z + d.z, s3 = a.w + b.w + c.w + d.w;
+        atomicAdd(out + n, s0); atomicAdd(out + n + 1, s1); atomicAdd(out + n + 2, s2); atomicAdd(out + n + 3, s3);
+        if (out2) { atomicAdd(out2 + n, s0); atomicAdd(out2 + n + 1, s1); atomicAdd(out2 + n + 2, s2); atomicAdd(out2 + n + 3, s3); }
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
     __shared__ float sh[4];
     float part = 0.f;
@@ -187,6 +213,13 @@ int colsum_add2(const float* X, int ld, int M, int N, float* out, float* out2, h
     MMQG_REQUIRE(M >= 0 && N >= 0 && ld >= N, "colsum_add: bad shape");
     if (M == 0 || N == 0) return 0;
     MMQG_REQUIRE(X && out, "colsum_add: null pointer");
+    if (N % 4 == 0 && ld % 4 == 0 && aligned16(X)) {
+        // ~16 rows per workgroup: enough workgroups to fill the chip on the [T*B][4H] gradients
+        const int rows_per_block = std::max(16, ceil_div(M, 512));
+        hipLaunchKernelGGL(colsum_add_vec4_kernel, dim3(ceil_div(N, 256), ceil_div(M, rows_per_block)), dim3(256), 0, s, X, ld, M,
+                           N, out, out2, rows_per_block);
+        return check_launch("colsum_add");
+    }
     int slices = std::min(64, std::max(1, M / 32));
     const int rows_per_block = ceil_div(M, slices);
     slices = ceil_div(M, rows_per_block);

@@ -392,6 +392,8 @@ class BatchedTrainer:
                            row_w=w["row_w"].data_ptr(), ctx_len_out=w["ctx_len"].data_ptr(),
                            tgt_len_out=w["tgt_len"].data_ptr(), n_frames_out=w["n_frames"].data_ptr())
         check(_lib.load().mmqg_pack_batch(C.byref(p), ops._stream()), "pack_batch")
+        # the gradient of the frame LSTM's input is only needed when a CNN produced that input
+        self.g_vid.dx = w["dfeats"].data_ptr() if self._cnn_on else None
 
     # ------------------------------------------------------------------------ one step
     # Two HIP streams: the recurrent time loops are latency-bound chains of small launches, the

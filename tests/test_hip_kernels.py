@@ -327,6 +327,13 @@ def test_colsum_and_reduce_sum(mm):
     out = torch.ones(2048, device="cuda")
     ops.colsum_add(dev(X), out)
     close(out, (X.double().sum(0) + 1).float(), what="colsum")
+    # unaligned width / padded rows (scalar kernel), a sub-block of a wider matrix (vector kernel, ld > N), few rows
+    for M, N, ld in ((37, 485, 488), (5, 64, 64), (130, 300, 812), (1, 4, 4)):
+        Xp = torch.randn(M, ld, generator=g)
+        o = torch.zeros(N, device="cuda")
+        Xd = dev(Xp)
+        _lib.check(_lib.load().mmqg_colsum_add(Xd.data_ptr(), ld, M, N, o.data_ptr(), ops._stream()))
+        close(o, Xp[:, :N].double().sum(0).float(), what=f"colsum {M}x{N} ld {ld}")
     x = torch.randn(1000, generator=g)
     r = torch.zeros(1, device="cuda")
     x_d = dev(x)
