@@ -64,6 +64,11 @@ class GradReducer:
         for name in self.buckets:
             self.reduce(name)
 
+    def discard(self) -> None:
+        """Wait for whatever is in flight and forget which buckets were reduced (after a pass whose
+        gradients are thrown away)."""
+        self.finish()
+
     def finish(self) -> None:
         for w in self._pending:
             w.wait()

@@ -81,10 +81,11 @@ class BatchedTrainer:
         self._flatten_parameters()
         self._allocate()
         self._describe()
-        # hipGraph replay only on a single GPU: eager launches are as fast here (the step is bound by
-        # the GPU-side dependency chain, not by the host) and keep RCCL entirely outside stream capture
+        # hipGraph replay also for data parallelism: an eager step keeps the host ~90% busy enqueueing, which
+        # is fragile with one such process per GPU; the graphs are cut where buckets become final and the
+        # all-reduces are issued between them, outside any capture
         self.distributed = exchange_needed(process_group)
-        self.use_graph = use_graph and not self.distributed
+        self.use_graph = use_graph
         self._graph = None
         self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
         self._side = torch.cuda.Stream(device=self.dev)
@@ -466,38 +467,21 @@ class BatchedTrainer:
         out = self.dec.out_layer
         ops.gemm(K_MAJOR, K_MAJOR, self.Td * B, V, H, htop, H, out.weight, H, w["logits"], V, bias=out.bias)
 
-    def _loss_and_backward(self):
+    def _loss_and_backward(self, part: str = "all"):
+        """part 'all': the whole backward with its fork/join branches.  The distributed graph step
+        splits it where gradient buckets become final: 'a' = loss, vocabulary projection, decoder loop,
+        then the decoder's weight gradients and the frame encoder's backward (decoder and frame-encoder
+        buckets are final); 'b' = text encoder backward (the rest)."""
         lib, w = _lib.load(), self.ws
         L, B, H, V, E = self.L, self.B, self.H, self.V, self.E
         R = self.Td * B
         s = ops._stream()
         logits = w["logits"]
-        check(lib.mmqg_ce_fwd_bwd(logits.data_ptr(), V, w["target"].data_ptr(), w["row_w"].data_ptr(), R, V,
-                                  w["loss_rows"].data_ptr(), w["argmax"].data_ptr(), logits.data_ptr(), V, s), "ce_fwd_bwd")
         out = self.dec.out_layer
         htop = w["hs_d"][L - 1, 1:].reshape(R, H)
         demb = self.dec.emb_layer.weight.grad
-        # vocabulary projection backward (logits now holds dlogits): weight gradient on the side stream
-        def vocab_side():            # weight gradient of the projection; the loss scalar is off the chain too
-            check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), ops._stream()), "reduce_sum")
-            ops.gemm(MN_MAJOR, MN_MAJOR, V, H, R, logits, V, htop, H, out.weight.grad, H, beta=1)
-            ops.colsum_add(logits, out.bias.grad)
-
-        def vocab_chain():
-            ops.gemm(K_MAJOR, MN_MAJOR, R, H, V, logits, V, out.weight, H, w["dhtop"], H)
-            self.g_dec.phase = 1
-            check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s), "decoder_seq_bwd(loop)")
-
-        if self.chain_first:
-            mark = self._mark()
-            vocab_chain()
-            with self._fork_from(mark):
-                vocab_side()
-        else:
-            with self._fork():
-                vocab_side()
-            vocab_chain()
-        self._join()
+        if part != "b":
+            self._backward_decoder(lib, w, s, logits, out, htop, R)
 
         def enc_side():              # decoder weight gradients, frame encoder backward
             s2 = ops._stream()
@@ -524,18 +508,49 @@ class BatchedTrainer:
             self.g_text.phase = 0
             ops.embedding_bwd(w["dxemb_c"].view(-1, E), w["ids_c"], demb)
 
-        if self.chain_first:
+        if part == "a":
+            enc_side()
+        elif part == "b":
+            enc_chain()
+        elif self.chain_first:
             mark = self._mark()
             enc_chain()
             with self._fork_from(mark):
                 enc_side()
+            self._join()
         else:
             with self._fork():
                 enc_side()
             enc_chain()
-        self._join()
-        if self.grad_hook:
+            self._join()
+        if self.grad_hook and part != "a":
             self.grad_hook(self, "all")
+
+    def _backward_decoder(self, lib, w, s, logits, out, htop, R):
+        V, H = self.V, self.H
+        check(lib.mmqg_ce_fwd_bwd(logits.data_ptr(), V, w["target"].data_ptr(), w["row_w"].data_ptr(), R, V,
+                                  w["loss_rows"].data_ptr(), w["argmax"].data_ptr(), logits.data_ptr(), V, s), "ce_fwd_bwd")
+        # vocabulary projection backward (logits now holds dlogits): weight gradient on the side stream
+        def vocab_side():            # weight gradient of the projection; the loss scalar is off the chain too
+            check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), ops._stream()), "reduce_sum")
+            ops.gemm(MN_MAJOR, MN_MAJOR, V, H, R, logits, V, htop, H, out.weight.grad, H, beta=1)
+            ops.colsum_add(logits, out.bias.grad)
+
+        def vocab_chain():
+            ops.gemm(K_MAJOR, MN_MAJOR, R, H, V, logits, V, out.weight, H, w["dhtop"], H)
+            self.g_dec.phase = 1
+            check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s), "decoder_seq_bwd(loop)")
+
+        if self.chain_first:
+            mark = self._mark()
+            vocab_chain()
+            with self._fork_from(mark):
+                vocab_side()
+        else:
+            with self._fork():
+                vocab_side()
+            vocab_chain()
+        self._join()
 
     def _refresh_transposes(self):
         """k-major copies of the recurrent weights for the backward loops, rebuilt every step
@@ -600,15 +615,21 @@ class BatchedTrainer:
         return loss
 
     # ------------------------------------------------------------------------ hipGraph
-    def _graph_body(self):
-        self.flat_g.zero_()
-        self._forward(True)
-        self._loss_and_backward()
+    def _graph_body(self, part: str = "all"):
+        if part != "b":
+            self.flat_g.zero_()
+            self._forward(True)
+        self._loss_and_backward(part)
 
     def _graph_step(self, batch):
         self.load_batch(batch)
         if self._graph is not None and self._graph_cnn != self._cnn_on:
             self._graph = None                                  # raw frames <-> features: different launch sequence
+        # single GPU: [zero, forward, loss, backward] | [Adam].  Data parallel: [zero, forward, loss, decoder
+        # backward, decoder weight gradients, frame encoder backward] | all-reduce(dec), all-reduce(vid) start |
+        # [text encoder backward] | all-reduce(rest), wait | [Adam]: RCCL stays outside every capture and the
+        # first two buckets travel while the text encoder's backward runs.
+        parts = ("a", "b") if self.distributed else ("all",)
         if self._graph is None:
             self._graph_cnn = self._cnn_on
             warm = torch.cuda.Stream()
@@ -617,21 +638,32 @@ class BatchedTrainer:
                                                           getattr(self.video, f"bn{i}").running_var)] if self._cnn_on else []
             saved = [b.clone() for b in bn_stats]
             with torch.cuda.stream(warm):      # warm-up outside capture (lazy code-object loads)
-                self._graph_body()
+                for part in parts:
+                    self._graph_body(part)
             torch.cuda.current_stream().wait_stream(warm)
             for b, v in zip(bn_stats, saved):  # the warm-up pass must not count as a training step
                 b.copy_(v)
             torch.cuda.synchronize()
-            # two graphs: [zero, forward, loss, backward] (with its internal fork/join branches) and
-            # [Adam]; the gradient all-reduce sits between them (RCCL is not captured)
-            self._graph = torch.cuda.CUDAGraph()
+            if self.distributed:
+                self.reducer.discard()          # the warm-up pass ran eagerly and may have queued reductions
+            self._graphs = []
+            pool = None
+            for part in parts:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    self._graph_body(part)
+                pool = g.pool()
+                self._graphs.append(g)
+            self._graph = self._graphs[0]
             self._graph_adam = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-                self._graph_body()
-            with torch.cuda.graph(self._graph_adam, pool=self._graph.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(self._graph_adam, pool=pool, capture_error_mode="thread_local"):
                 self._adam()
-        self._graph.replay()
+        self._graphs[0].replay()
         self._count_bn_batches()
+        if self.distributed:
+            self.reducer.reduce("dec")
+            self.reducer.reduce("vid")
+            self._graphs[1].replay()
         self._allreduce()
         self._graph_adam.replay()
         return self.ws["loss"]
