@@ -129,5 +129,35 @@ int main() {
         report(cs_.name, tr, cs_.nwg, ms * 1e3f / chain);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
+    // two independent chains of single-job forward layer-steps on two streams: do latency-bound kernels overlap?
+    {
+        hipStream_t s2; CK(hipStreamCreate(&s2));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_skinny_trace), &null_trace, sizeof(null_trace)));
+        float* hs2 = dalloc((size_t)L * (chain + 2) * B * H, 0.5f);
+        float* cs2 = dalloc((size_t)L * (chain + 2) * B * H, 0.5f);
+        float* gates2 = dalloc((size_t)L * B * 4 * H, 0.5f);
+        auto run = [&](hipStream_t st, float* hsb, float* csb, float* gb, int t) {
+            mmqg::SkinnyFwdJob j = fwd_job(1, t);
+            j.pairs[0].A = hsb + (size_t)0 * (chain + 2) * BH + (size_t)(t + 1) * BH;
+            j.pairs[1].A = hsb + (size_t)1 * (chain + 2) * BH + (size_t)t * BH;
+            j.cell.gates = gb + (size_t)B * 4 * H;
+            j.cell.h_prev = j.pairs[1].A; j.cell.c_prev = csb + (size_t)1 * (chain + 2) * BH + (size_t)t * BH;
+            j.cell.h_out = hsb + (size_t)1 * (chain + 2) * BH + (size_t)(t + 1) * BH;
+            j.cell.c_out = csb + (size_t)1 * (chain + 2) * BH + (size_t)(t + 1) * BH;
+            if (mmqg::skinny_cell_fwd_multi(&j, 1, st)) exit(3);
+        };
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int mode = 0; mode < 2; ++mode) {       // 0: one chain, 1: two chains side by side
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0, s));
+                hipEvent_t f; CK(hipEventCreate(&f)); CK(hipEventRecord(f, s)); CK(hipStreamWaitEvent(s2, f, 0));
+                for (int t = 0; t < chain; ++t) { run(s, hs, cs, gates, t); if (mode) run(s2, hs2, cs2, gates2, t); }
+                hipEvent_t jn; CK(hipEventCreate(&jn)); CK(hipEventRecord(jn, s2)); CK(hipStreamWaitEvent(s, jn, 0));
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep) printf("%s of %d forward layer-steps: %.2f us per step\n", mode ? "TWO chains side by side" : "one chain", chain, ms * 1e3f / chain);
+            }
+        }
+    }
     return 0;
 }
