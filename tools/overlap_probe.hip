@@ -24,6 +24,23 @@ static float chain_ms(hipStream_t a, float* buf, int n, int iters, int grid_tiny
     return ms;
 }
 
+// background kernel that keeps writing: mode 0 plain stores, 1 nontemporal stores, 2 atomic adds, 3 loads only
+__global__ __launch_bounds__(256) void writer(float* buf, size_t n, long long ticks, int mode) {
+    const long long t0 = wall_clock64();
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    float acc = 0.f;
+    while (wall_clock64() - t0 < ticks) {
+        if (mode == 0) buf[i] = acc;
+        else if (mode == 1) __builtin_nontemporal_store(acc, buf + i);
+        else if (mode == 2) atomicAdd(buf + i, 1.0f);
+        else acc += buf[i];
+        acc += 1.f;
+        i += stride; if (i >= n) i -= n;
+    }
+    if (mode == 3 && acc == 12345.f) buf[0] = acc;
+}
+
 __global__ void stamp(unsigned long long* out) { if (threadIdx.x == 0 && blockIdx.x == 0) *out = wall_clock64(); }
 
 // the same experiment as ONE hipGraph: [long kernels on stream b] beside [stamp, chain of tiny kernels, stamp on stream a]
@@ -68,6 +85,17 @@ int main() {
         CK(hipStreamSynchronize(b));
         printf("beside [%s]: %.2f us per tiny kernel (chain took %.2f ms)\n", c.name, ms * 1e3 / iters, ms);
         graph_case(a, b, buf, n, buf2, c.wgs, c.threads, c.ticks, c.launches, iters, c.name);
+    }
+    {
+        const size_t nw = (size_t)64 << 20;      // 256 MB of floats
+        float* big; CK(hipMalloc(&big, nw * 4)); CK(hipMemset(big, 0, nw * 4));
+        const char* names[4] = {"plain stores", "nontemporal stores", "atomic adds", "loads only"};
+        for (int mode = 0; mode < 4; ++mode) {
+            hipLaunchKernelGGL(writer, dim3(512), dim3(256), 0, b, big, nw, 300000, mode);
+            const float ms = chain_ms(a, buf, n, iters, 128);
+            CK(hipStreamSynchronize(b));
+            printf("beside [1 kernel of 512 workgroups streaming %s over 256 MB for 3 ms]: %.2f us per tiny kernel\n", names[mode], ms * 1e3 / iters);
+        }
     }
     return 0;
 }
