@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 // Several independent products of one layout in ONE launch (weight gradients of a layer stack): grid.z =
 // problem x k-slice, the x/y extent is the largest problem's tile grid, every problem accumulates (beta = 1)
 // so k-slices simply add atomically.
-constexpr int kMaxGroup = 6;
+constexpr int kMaxGroup = 10;
 struct GemmBatch { GemmArgs p[kMaxGroup]; int split; };
 
 template <int BM, int BN, int BK, bool A_K, bool B_K>
@@ -314,6 +314,20 @@ int launch(const GemmArgs& a, int a_layout, int b_layout, hipStream_t s) {
     else
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, false, true>), grid, block, 0, s, a);
     return mmqg::check_launch("gemm_f32");
+}
+
+// K split of a 128x128-tiled product: the number of rounds the workgroups need on the chip's resident
+// slots times the length of one workgroup's k-loop (plus a fixed per-workgroup cost in k-tile units:
+// pipeline fill, epilogue, atomics), minimised over 1, 2, 4, ... — e.g. 576 tiles x 80 k-tiles on 768 slots:
+// split 2 = 2 rounds x 46, split 4 = 3 rounds x 26, so 4 wins although 2 already "fills" the chip.
+inline int pick_split(int64_t tiles, int nk, int slots, int fixed, int max_split, int min_kt) {
+    int best = 1;
+    int64_t best_cost = ((tiles + slots - 1) / slots) * (int64_t)(nk + fixed);
+    for (int sp = 2; sp <= max_split && nk / sp >= min_kt; sp *= 2) {
+        const int64_t cost = ((tiles * sp + slots - 1) / slots) * (int64_t)((nk + sp - 1) / sp + fixed);
+        if (cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    return best;
 }
 
 inline bool can_vec(const float* p, int ld) { return p && mmqg::aligned16(p) && (ld % 4 == 0); }
@@ -382,6 +396,8 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
         if (small) {      // aim for ~384 workgroups, at least 4 k-tiles per slice
             const int64_t tiles = (int64_t)ceil_div(M, 64) * ceil_div(N, 64);
             while (tiles * split_k < 384 && nk / (split_k * 2) >= 4 && split_k < 16) split_k *= 2;
+        } else if (heur == 3) {     // cost model (rounds x k-loop length), as for the grouped launches
+            split_k = pick_split(big_tiles, nk, bk == 16 ? 768 : 512, bk == 16 ? 6 : 3, 16, 8);
         } else if (heur != 1) {
             while (big_tiles * split_k < 448 && nk / (split_k * 2) >= 8 && split_k < 16) split_k *= 2;
         }
@@ -451,8 +467,7 @@ int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n
             nk_min = std::min(nk_min, ceil_div(q.K, BK));
         }
         // k-slices (atomic adds; every problem accumulates anyway): ~3 workgroups per CU, >= 8 k-tiles each
-        int split = 1;
-        while (tiles * split < 640 && nk_min / (split * 2) >= 8 && split < 8) split *= 2;
+        const int split = pick_split(tiles, nk_min, 768, 6, 8, 8);      // BK = 16: three workgroups per CU
         for (int i = 0; i < ng; ++i) b.p[i].split_k = split;
         b.split = split;
         hipLaunchKernelGGL((gemm_f32_grouped_kernel<128, 128, BK, false, false>), dim3(tx, ty, ng * split), dim3(256), 0, s, b);
