@@ -32,7 +32,7 @@ _tv = types.ModuleType("torchvision")
 _tv.models = types.ModuleType("torchvision.models")
 sys.modules.setdefault("torchvision", _tv)
 sys.modules.setdefault("torchvision.models", _tv.models)
-from model.decoder import AttnDecoder  # noqa: E402
+from model.decoder import AttnDecoder, Decoder  # noqa: E402
 from model.encoder import TextEncoder, VideoConvLstmEncoder  # noqa: E402
 
 torch.set_num_threads(1)
@@ -168,6 +168,29 @@ def make_small():
     print("small_model.npz:", len(out), "arrays")
 
 
+def make_plain_decoder():
+    """The older non-attention ``Decoder`` (decoder.py:7-47): a 5-token teacher-forced call, eval mode
+    (dropout off), forward outputs and every parameter gradient of sum(logits * probe)."""
+    torch.manual_seed(21)
+    V, E, Dav, H, L, n = 37, 12, 10, 16, 2, 5
+    emb = torch.nn.Embedding(V, E)
+    dec = Decoder(L, 0.3, H, V, E, Dav, emb).eval()
+    text = torch.randint(0, V, (1, n))
+    av = torch.randn(1, Dav)
+    h0, c0 = torch.randn(L, 1, H) * 0.3, torch.randn(L, 1, H) * 0.3
+    probe = torch.randn(n, 1, V)
+    logits, (h, c) = dec(text, av, (h0, c0))
+    ((logits * probe).sum() + (h * 0.5).sum() + (c * 0.25).sum()).backward()
+    out = dict(text=text.numpy(), av=av.numpy(), h0=h0.numpy(), c0=c0.numpy(), probe=probe.numpy(),
+               logits=logits.detach().numpy().copy(), h=h.detach().numpy().copy(), c=c.detach().numpy().copy(),
+               dims=np.array([V, E, Dav, H, L, n]))
+    out.update(npz_state("sd", dec.state_dict()))
+    for k, p in dec.named_parameters():
+        out[f"grad/{k}"] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "plain_decoder.npz"), **out)
+    print("plain_decoder.npz", len(out), "arrays")
+
+
 def make_default_dims():
     """config.py default widths (E=300,H=512,L=3,Lt=283,Lav=101,Da=128,Dv=512), tiny vocab.
     Weights come from ``seeded_params`` so only seeds + outputs are stored."""
@@ -216,3 +239,4 @@ def make_default_dims():
 if __name__ == "__main__":
     make_small()
     make_default_dims()
+    make_plain_decoder()

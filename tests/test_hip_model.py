@@ -195,6 +195,26 @@ def test_default_dims_decoder_text_and_feature_bypass(mm):
         close(hid[0], z["dec_h"]); close(hid[1], z["dec_c"])
 
 
+def test_plain_decoder_matches_reference_forward_and_backward(mm):
+    """The older non-attention ``Decoder`` (decoder.py:7-47) on the HIP kernels against the reference's own
+    outputs: logits of a 5-token call, final state, every parameter gradient."""
+    from model.decoder import Decoder
+    z = load_npz("plain_decoder.npz")
+    V, E, Dav, H, L, n = (int(x) for x in z["dims"])
+    emb = torch.nn.Embedding(V, E)
+    dec = Decoder(L, 0.3, H, V, E, Dav, emb).eval()
+    dec.load_state_dict(state_from(z, "sd"))
+    dec.cuda()
+    t = lambda k: torch.from_numpy(np.array(z[k])).cuda()          # noqa: E731
+    logits, (h, c) = dec(t("text"), t("av"), (t("h0"), t("c0")))
+    close(logits, z["logits"], what="logits")
+    close(h, z["h"], what="h")
+    close(c, z["c"], what="c")
+    ((logits * t("probe")).sum() + (h * 0.5).sum() + (c * 0.25).sum()).backward()
+    for k, p in dec.named_parameters():
+        close(p.grad, z[f"grad/{k}"], what=f"grad {k}")
+
+
 def test_modules_refuse_cpu_tensors(mm):
     emb = torch.nn.Embedding(20, 8)
     dec = mm["AttnDecoder"](2, 0.0, 8, 20, 8, 8, 4, emb, 5, 3, "cpu")
