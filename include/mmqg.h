@@ -150,6 +150,9 @@ int mmqg_counter_add(int32_t* counter, int delta, mmqg_stream stream);
  * the backward time loops; refresh after every optimizer step. */
 int mmqg_transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst,
                        mmqg_stream stream);
+/* several transposes in ONE launch (all recurrent weights of a model after an optimizer step) */
+typedef struct { const float* src; int32_t ld_src; int32_t rows; int32_t cols; float* dst; int32_t ld_dst; } mmqg_transpose_job;
+int mmqg_transpose_f32_batch(const mmqg_transpose_job* jobs, int n, mmqg_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole-sequence executors: one call enqueues every kernel of a time loop.

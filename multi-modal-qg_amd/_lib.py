@@ -94,6 +94,11 @@ class DecoderSeqGrad(C.Structure):
                 ("phase", C.c_int32), ("dh_pre", c_f)]
 
 
+class TransposeJob(C.Structure):
+    _fields_ = [("src", c_f), ("ld_src", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dst", c_f),
+                ("ld_dst", C.c_int32)]
+
+
 class GemmProblem(C.Structure):
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("A", c_f), ("lda", C.c_int32), ("B", c_f),
                 ("ldb", C.c_int32), ("C", c_f), ("ldc", C.c_int32), ("beta", C.c_int32)]
@@ -154,6 +159,7 @@ SIGNATURES = {
     "mmqg_adam_step": [c_f, c_f, c_f, c_f, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, c_f, c_fl, c_f],
     "mmqg_counter_add": [c_f, c_i, c_f],
     "mmqg_transpose_f32": [c_f, c_i, c_i, c_i, c_f, c_i, c_f],
+    "mmqg_transpose_f32_batch": [C.POINTER(TransposeJob), c_i, c_f],
     "mmqg_lstm_seq_fwd": [C.POINTER(LstmSeq), c_f],
     "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
     "mmqg_decoder_decode_run": [C.POINTER(DecoderDecode), c_f],

@@ -119,6 +119,10 @@ int mmqg_transpose_f32(const float* src, int ld_src, int rows, int cols, float* 
     return transpose_f32(src, ld_src, rows, cols, dst, ld_dst, S(stream));
 }
 
+int mmqg_transpose_f32_batch(const mmqg_transpose_job* jobs, int n, mmqg_stream stream) {
+    return transpose_f32_batch(jobs, n, S(stream));
+}
+
 int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream) {
     MMQG_REQUIRE(d, "mmqg_lstm_seq_fwd: null descriptor");
     return lstm_seq_fwd(*d, S(stream));

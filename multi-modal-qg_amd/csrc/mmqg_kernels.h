@@ -78,6 +78,7 @@ int skinny_cell_bwd_plus(const SkinnyBwdJob& cell, const SkinnyPlainJob* extra, 
 int skinny_cell_fwd_multi(const SkinnyFwdJob* jobs, int njobs, hipStream_t s);
 int skinny_cell_bwd_multi(const SkinnyBwdJob* jobs, int njobs, hipStream_t s);
 int transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s);
+int transpose_f32_batch(const mmqg_transpose_job* jobs, int n, hipStream_t s);
 
 // ---- attention.hip --------------------------------------------------------------------
 int attn_softmax_context_fwd(const mmqg_attn_values& v, const float* scores, int ld_s, float* attn, int ld_a,

@@ -331,6 +331,28 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+constexpr int kMaxTranspose = 16;
+struct TransposeBatch { mmqg_transpose_job job[kMaxTranspose]; };
+
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch b) {
+    __shared__ float tile[32][33];
+    const mmqg_transpose_job& j = b.job[blockIdx.z];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    if (r0 >= j.rows || c0 >= j.cols) return;      // the grid is the bounding box of the jobs
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, cc = c0 + tx;
+        tile[ty + i][tx] = (r < j.rows && cc < j.cols) ? j.src[(int64_t)r * j.ld_src + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int cc = c0 + ty + i, r = r0 + tx;
+        if (cc < j.cols && r < j.rows) j.dst[(int64_t)cc * j.ld_dst + r] = tile[tx][ty + i];
+    }
+}
+
 bool pair_ok(const mmqg::SkinnyPair& p) {
     return p.A && p.B && p.K > 0 && p.K % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 && mmqg::aligned16(p.A) &&
            mmqg::aligned16(p.B);
@@ -484,6 +506,26 @@ int skinny_cell_bwd(const SkinnyPair* pairs, int npairs, const CellBwd& f, hipSt
     for (int i = 0; i < npairs; ++i) j.pairs[i] = pairs[i];
     j.npairs = npairs; j.cell = f;
     return skinny_cell_bwd_multi(&j, 1, s);
+}
+
+int transpose_f32_batch(const mmqg_transpose_job* jobs, int n, hipStream_t s) {
+    MMQG_REQUIRE(n >= 0 && (n == 0 || jobs), "transpose_f32_batch: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += kMaxTranspose) {
+        TransposeBatch b{};
+        const int m = std::min(kMaxTranspose, n - i0);
+        int gx = 0, gy = 0;
+        for (int i = 0; i < m; ++i) {
+            const mmqg_transpose_job& j = jobs[i0 + i];
+            MMQG_REQUIRE(j.rows >= 0 && j.cols >= 0 && (j.rows == 0 || j.cols == 0 || (j.src && j.dst && j.ld_src >= j.cols && j.ld_dst >= j.rows)),
+                         "transpose_f32_batch: bad job %d", i0 + i);
+            b.job[i] = j;
+            gx = std::max(gx, ceil_div(j.cols, 32)); gy = std::max(gy, ceil_div(j.rows, 32));
+        }
+        if (gx == 0 || gy == 0) continue;
+        hipLaunchKernelGGL(transpose_batch_kernel, dim3(gx, gy, m), dim3(256), 0, s, b);
+        MMQG_TRY(check_launch("transpose_f32_batch"));
+    }
+    return 0;
 }
 
 int transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s) {

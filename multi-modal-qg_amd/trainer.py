@@ -88,6 +88,7 @@ class BatchedTrainer:
         self.use_graph = use_graph
         self._graph = None
         self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
+        self._tr_jobs = None
         self._side = torch.cuda.Stream(device=self.dev)
         self.chain_first = os.environ.get("MMQG_SIDE_FIRST", "0") != "1"
         if os.environ.get("MMQG_NO_AHEAD", "0") != "1":      # look-ahead recurrent products in the decoder's backward loop
@@ -553,24 +554,30 @@ class BatchedTrainer:
         self._join()
 
     def _refresh_transposes(self):
-        """k-major copies of the recurrent weights for the backward loops, rebuilt every step
-        (9 small launches on the side stream) so externally loaded weights are honoured."""
-        lib, s, w = _lib.load(), ops._stream(), self.ws
-        H, L, Hv = self.H, self.L, self.Hv
+        """k-major copies of the recurrent weights for the backward loops, rebuilt every step (ONE launch
+        on the side stream) so externally loaded weights are honoured."""
+        if self._tr_jobs is None:
+            w, H, L, Hv = self.ws, self.H, self.L, self.Hv
+            jobs = []
 
-        def tr(src_ptr, ld_src, rows, cols, dst, ld_dst):
-            check(lib.mmqg_transpose_f32(src_ptr, ld_src, rows, cols, dst.data_ptr(), ld_dst, s), "transpose_f32")
+            def tr(src_ptr, ld_src, rows, cols, dst, ld_dst):
+                jobs.append((src_ptr, ld_src, rows, cols, dst.data_ptr(), ld_dst))
 
-        tr(self.video.lstm.weight_hh_l0.data_ptr(), Hv, 4 * Hv, Hv, w["whhT_v"][0], 4 * Hv)
-        for l in range(L):
-            tr(getattr(self.text.lstm, f"weight_hh_l{l}").data_ptr(), H, 4 * H, H, w["whhT_t"][l], 4 * H)
-            tr(getattr(self.dec.lstm, f"weight_hh_l{l}").data_ptr(), H, 4 * H, H, w["whhT_d"][l], 4 * H)
-            if l > 0:
-                tr(getattr(self.dec.lstm, f"weight_ih_l{l}").data_ptr(), H, 4 * H, H, w["wihT_d"][l], 4 * H)
-                tr(getattr(self.text.lstm, f"weight_ih_l{l}").data_ptr(), H, 4 * H, H, w["wihT_t"][l], 4 * H)
-        In0 = self.E + self.Cw
-        tr(self.dec.lstm.weight_ih_l0.data_ptr() + 4 * self.E, In0, 4 * H, self.Cw, w["wih0cT"], 4 * H)
-        tr(self.dec.text_attn.weight.data_ptr() + 4 * self.E, self.E + H, self.S, H, w["wattn_hT"], self.ldS)
+            tr(self.video.lstm.weight_hh_l0.data_ptr(), Hv, 4 * Hv, Hv, w["whhT_v"][0], 4 * Hv)
+            for l in range(L):
+                tr(getattr(self.text.lstm, f"weight_hh_l{l}").data_ptr(), H, 4 * H, H, w["whhT_t"][l], 4 * H)
+                tr(getattr(self.dec.lstm, f"weight_hh_l{l}").data_ptr(), H, 4 * H, H, w["whhT_d"][l], 4 * H)
+                if l > 0:
+                    tr(getattr(self.dec.lstm, f"weight_ih_l{l}").data_ptr(), H, 4 * H, H, w["wihT_d"][l], 4 * H)
+                    tr(getattr(self.text.lstm, f"weight_ih_l{l}").data_ptr(), H, 4 * H, H, w["wihT_t"][l], 4 * H)
+            In0 = self.E + self.Cw
+            tr(self.dec.lstm.weight_ih_l0.data_ptr() + 4 * self.E, In0, 4 * H, self.Cw, w["wih0cT"], 4 * H)
+            tr(self.dec.text_attn.weight.data_ptr() + 4 * self.E, self.E + H, self.S, H, w["wattn_hT"], self.ldS)
+            arr = (_lib.TransposeJob * len(jobs))()
+            for a, j in zip(arr, jobs):
+                a.src, a.ld_src, a.rows, a.cols, a.dst, a.ld_dst = j
+            self._tr_jobs = arr
+        check(_lib.load().mmqg_transpose_f32_batch(self._tr_jobs, len(self._tr_jobs), ops._stream()), "transpose_f32_batch")
 
     def _adam(self):
         lib, s = _lib.load(), ops._stream()

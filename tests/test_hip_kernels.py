@@ -430,6 +430,19 @@ def test_transpose(mm):
     _lib.check(_lib.load().mmqg_transpose_f32(s_d.data_ptr(), 136, 77, 130, dst.data_ptr(), 80, ops._stream()))
     assert torch.equal(dst[:, :77].cpu(), src[:, :130].t())
     assert torch.all(dst[:, 77:] == -1.0)
+    # several matrices of different shapes in one launch (17 jobs: more than one batch of 16)
+    shapes = [(77, 130, 6, 3), (2048, 512, 0, 0), (5, 3, 1, 2), (33, 64, 0, 31)] * 4 + [(1, 1, 0, 0)]
+    jobs = (_lib.TransposeJob * len(shapes))()
+    keep = []
+    for j, (r, c, ps, pd) in zip(jobs, shapes):
+        a = torch.randn(r, c + ps, generator=g)
+        a_d, d_d = dev(a), torch.full((c, r + pd), -2.0, device="cuda")
+        keep.append((a, a_d, d_d, r, c))
+        j.src, j.ld_src, j.rows, j.cols, j.dst, j.ld_dst = a_d.data_ptr(), c + ps, r, c, d_d.data_ptr(), r + pd
+    _lib.check(_lib.load().mmqg_transpose_f32_batch(jobs, len(shapes), ops._stream()))
+    torch.cuda.synchronize()
+    for a, a_d, d_d, r, c in keep:
+        assert torch.equal(d_d[:, :r].cpu(), a[:, :c].t()) and torch.all(d_d[:, r:] == -2.0)
 
 
 # ------------------------------------------------------------------------------ edge cases

@@ -45,6 +45,7 @@ def test_ctypes_structs_match_the_c_layout(lib_mod, tmp_path):
               "mmqg_decoder_seq_grad": ("DecoderSeqGrad", ["dhtop", "ld_ds", "dxemb", "db_hh", "n_text_rows", "dvideo_stride_b", "phase", "dh_pre"]),
               "mmqg_decoder_decode": ("DecoderDecode", ["values", "emb_table", "b_hh", "w_out", "start_id", "seed", "target",
                                                         "ids", "ld_attn", "xemb", "hs", "logits", "keep_logits"]),
+              "mmqg_transpose_job": ("TransposeJob", ["src", "ld_src", "rows", "cols", "dst", "ld_dst"]),
               "mmqg_gemm_problem": ("GemmProblem", ["M", "K", "A", "lda", "B", "C", "ldc", "beta"]),
               "mmqg_batch_pack": ("BatchPack", ["B", "audio_rows", "frame_inner", "frames", "n_frames", "start_id", "feats",
                                                 "audio_stride_b", "row_w", "n_frames_out"]),
