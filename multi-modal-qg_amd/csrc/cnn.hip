@@ -314,32 +314,40 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdK a) {
 
 // dconv = relu'(y) * gamma*invstd * (dz' - mean(dz') - xhat * mean(dz' xhat)), dz' = routed pooled gradient
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(BnBwdK a) {
+    __shared__ float coef[5];      // per (question, channel): mean, invstd, gamma*invstd, mean(dz'), mean(dz' xhat)
+    __shared__ int frame_valid;
     const int Hz = a.pool ? a.Hy / 3 : a.Hy, Wz = a.pool ? a.Wy / 3 : a.Wy;
-    const int pix = blockIdx.y * 256 + threadIdx.x;             // grid: (frame*channel planes, pixel blocks)
+    const int n = blockIdx.x / a.C, c = blockIdx.x % a.C;        // grid: (frame*channel planes, pixel blocks)
+    if (threadIdx.x == 0) {        // the plane's coefficients once per workgroup (two f64 divisions), not per pixel
+        int b, t; frame_bt(n, a.N, a.T, a.tm, b, t);
+        const int nf = a.n_frames ? a.n_frames[b] : a.T;
+        frame_valid = t < nf;
+        const int64_t bc = (int64_t)b * a.C + c;
+        const double cnt = (double)nf * a.Hy * a.Wy;
+        const float inv = a.invstd[bc];
+        coef[0] = a.mean[bc]; coef[1] = inv; coef[2] = a.gamma[c] * inv;
+        coef[3] = cnt > 0 ? (float)(a.sums[bc * 2] / cnt) : 0.f;
+        coef[4] = cnt > 0 ? (float)(a.sums[bc * 2 + 1] / cnt) : 0.f;
+    }
+    __syncthreads();
+    const int pix = blockIdx.y * 256 + threadIdx.x;
     if (pix >= a.Hy * a.Wy) return;
-    const int n = blockIdx.x / a.C, c = blockIdx.x % a.C;
     const int x = pix % a.Wy, yq = pix / a.Wy;
     const int64_t i = (int64_t)blockIdx.x * a.Hy * a.Wy + pix;
-    int b, t; frame_bt(n, a.N, a.T, a.tm, b, t);
-    const int nf = a.n_frames ? a.n_frames[b] : a.T;
-    if (t >= nf) { a.dconv[i] = 0.f; return; }
+    if (!frame_valid) { a.dconv[i] = 0.f; return; }
     const float yv = a.y[i];
     float d = 0.f;
     if (a.pool) {
         const int py = yq / 3, px = x / 3;
         if (py < Hz && px < Wz) {
-            const int64_t pi = ((int64_t)n * a.C + c) * Hz * Wz + (int64_t)py * Wz + px;
-            if (a.argmax[pi] == (yq % 3) * 3 + (x % 3)) d = a.dz[pi];
+            const int64_t pi = (int64_t)blockIdx.x * Hz * Wz + (int64_t)py * Wz + px;
+            if (a.argmax[pi] == (yq - 3 * py) * 3 + (x - 3 * px)) d = a.dz[pi];
         }
     } else {
         d = a.dz[i];
     }
-    const int64_t bc = (int64_t)b * a.C + c;
-    const float inv = a.invstd[bc];
-    const double cnt = (double)nf * a.Hy * a.Wy;
-    const float m1 = (float)(a.sums[bc * 2] / cnt), m2 = (float)(a.sums[bc * 2 + 1] / cnt);
-    const float xh = (yv - a.mean[bc]) * inv;
-    const float dy = a.gamma[c] * inv * (d - m1 - xh * m2);
+    const float xh = (yv - coef[0]) * coef[1];
+    const float dy = coef[2] * (d - coef[3] - xh * coef[4]);
     a.dconv[i] = yv > 0.f ? dy : 0.f;
 }
 
