@@ -2,17 +2,24 @@
 """Benchmark of the hot path: training questions/s (forward + backward + optimizer) of the
 multimodal encoder -> attention decoder step on synthetic tensors, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config4|config5|...]
 
-For N > 1 launch with ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``
-(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment); every rank trains its own
-shard of the global batch (weak scaling, B questions per GPU) and gradients are all-reduced
-over RCCL.  Rank 0 prints ONE JSON line.
+N > 1: either launch it under ``python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or just run
+``python bench.py --gpus N``: with no WORLD_SIZE in the environment the script starts that
+launcher itself as a child process — before anything here has touched the GPU — and relays rank
+0's JSON line and the child's exit code.  Every rank trains its own shard of the global batch
+(weak scaling, B questions per GPU) and gradients are all-reduced over RCCL.  Rank 0 prints ONE
+JSON line.
 
 Besides throughput the line carries
   roofline      the decoder-attention kernel (softmax + context, the HBM-bound kernel BASELINE.json's
                 metric names): algorithmic bytes per launch / average launch duration, measured here
-                with HIP events on the launch stream over back-to-back launches on the step's buffers;
+                with HIP events on the launch stream.  Two durations: ``achieved`` = back-to-back
+                launches on the step's own buffers (what the step sees: the 54 MB value tensor of a
+                batch is re-read every decode step and stays in the 256 MiB Infinity Cache), and
+                ``achieved_beyond_mall`` = the same launches rotated over enough distinct value
+                tensors (> 2 x 256 MiB) that every row comes from HBM;
   roofline_mfma the vocabulary-projection GEMM (fp32 MFMA), same method;
   cpu_baseline  the CPU oracle (``oracle/``: the reference's batch-1 loop restated, kind "port")
                 timed on this box's host cores on a bounded sample of the same workload.
@@ -21,8 +28,11 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,9 +43,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA (spec)
+MALL_BYTES = 256 << 20         # Infinity Cache
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -46,9 +57,42 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
     ap.add_argument("--kernel-iters", type=int, default=200, help="launches per kernel-duration measurement")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------- self-launch
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(gpus: int, argv, port: int):
+    """The one-node launch the driver would use: one rank per GPU, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch_needed(gpus: int, env) -> bool:
+    return gpus > 1 and "WORLD_SIZE" not in env
+
+
+def self_launch(a, argv) -> int:
+    """Start the N ranks as a child process tree.  Nothing in this process has touched the GPU yet
+    (``import torch`` and ``device_count`` do not), and this process never execs: it waits for the
+    launcher and hands its exit code on."""
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but this node shows {have} device(s)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launcher_command(a.gpus, argv, free_port())
+    return subprocess.run(cmd, env=env).returncode
+
+
+# --------------------------------------------------------------------------------- rooflines
 def attention_bytes(w, B):
     """Algorithmic bytes of ONE attention launch (forward, one decode step, B questions), SURVEY §8d:
     value rows + query-side i/o; the score matrix is counted by the score GEMM, not here."""
@@ -61,8 +105,8 @@ def attention_bytes(w, B):
 def time_launches(fn, iters):
     """Average duration of fn() launches enqueued back to back, by HIP events on the current
     stream (the stream the kernels are launched on)."""
-    for _ in range(5):
-        fn(0)
+    for i in range(5):
+        fn(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -71,6 +115,27 @@ def time_launches(fn, iters):
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3      # seconds
+
+
+def source_sha(rel):
+    with open(os.path.join(ROOT, rel), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def recorded_traffic(workload_key):
+    """PMC-measured HBM-side bytes per attention launch (profiles/attn_traffic.json, written by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes).  Only a record
+    taken on the kernel source that is loaded now counts; anything else reports null."""
+    tpath = os.path.join(ROOT, "profiles", "attn_traffic.json")
+    try:
+        rec = json.load(open(tpath)).get(workload_key)
+    except Exception:
+        return None, "no profiles/attn_traffic.json"
+    if not rec:
+        return None, f"no PMC record for {workload_key}"
+    if rec.get("source_sha") != source_sha("multi-modal-qg_amd/csrc/attention.hip"):
+        return None, "PMC record was taken on a different attention.hip"
+    return rec.get("hbm_bytes_per_launch"), f"{rec.get('kernel')} grid {rec.get('grid')}"
 
 
 def kernel_rooflines(tr, w, iters):
@@ -87,16 +152,37 @@ def kernel_rooflines(tr, w, iters):
                                                      cx[t].data_ptr(), Cw, s))
     dt = time_launches(attn, iters)
     nbytes, _ = attention_bytes(w, B)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "attn_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(w.name.split(":")[0], {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roof = {"kernel": "attn_softmax_context_fwd_kernel", "bound": "hbm", "achieved": round(nbytes / dt / 1e9, 1),
+    key = w.name.split(":")[0].split(" ")[0]
+    traffic, note = recorded_traffic(key)
+
+    # the same launch with every value row coming from HBM: rotate over distinct value tensors whose total
+    # is more than twice the Infinity Cache, so a tensor is long evicted when its turn comes again
+    vbytes = ws["values"].numel() * 4
+    n_rot = max(3, -(-2 * MALL_BYTES // vbytes) + 1)
+    rot = torch.randn(n_rot, ws["values"].numel(), device=ws["values"].device)
+    descs = []
+    for r in range(n_rot):
+        v = type(d.values)()
+        C.memmove(C.addressof(v), C.addressof(d.values), C.sizeof(v))
+        base = rot[r].data_ptr()
+        v.text, v.audio, v.video = base, base + 4 * tr.off_audio, base + 4 * tr.off_video
+        descs.append(v)
+
+    def attn_cold(i):
+        t = i % Td
+        _lib.check(lib.mmqg_attn_softmax_context_fwd(C.byref(descs[i % n_rot]), sc[t].data_ptr(), ldS, at[t].data_ptr(),
+                                                     ldS, cx[t].data_ptr(), Cw, s))
+    dtc = time_launches(attn_cold, max(iters, 4 * n_rot))
+    del rot
+    roof = {"kernel": "attn_softmax_context_fwd_kernel<64>", "bound": "hbm", "achieved": round(nbytes / dt / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "bytes_per_launch": nbytes, "us_per_launch": round(dt * 1e6, 2)}
+            "traffic": traffic, "traffic_source": note, "bytes_per_launch": nbytes, "us_per_launch": round(dt * 1e6, 2),
+            "served_from": "in situ: the step's own value tensor, re-read every decode step (Infinity Cache resident "
+                           "when it is < 256 MiB)",
+            "achieved_beyond_mall": round(nbytes / dtc / 1e9, 1),
+            "frac_beyond_mall": round(nbytes / dtc / 1e9 / HBM_PEAK_GBS, 4),
+            "us_per_launch_beyond_mall": round(dtc * 1e6, 2),
+            "beyond_mall_working_set_bytes": int(n_rot * vbytes)}
     # vocabulary projection: logits[Td*B, V] = h_top * W_out^T + b
     R, H, V = Td * B, tr.H, tr.V
     htop = ws["hs_d"][tr.L - 1, 1:].reshape(R, H)
@@ -107,17 +193,19 @@ def kernel_rooflines(tr, w, iters):
         ops.gemm(0, 0, R, V, H, htop, H, out.weight, H, scratch, V, bias=out.bias)
     dtp = time_launches(proj, max(10, iters // 10))
     flops = 2.0 * R * H * V
-    mfma = {"kernel": "gemm_f32_kernel<128,128,32> (vocab projection fwd)", "bound": "mfma",
+    mfma = {"kernel": "gemm_f32 (vocab projection fwd)", "bound": "mfma",
             "achieved": round(flops / dtp / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flops / dtp / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
             "flops_per_launch": flops, "us_per_launch": round(dtp * 1e6, 2)}
     return roof, mfma
 
 
+# ------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(w, budget_s):
     """The reference's semantics on the host cores: batch-1 loop of zero_grad -> encoders ->
     per-token decoder with teacher forcing -> summed CE -> backward -> Adam (train.py:149-181),
-    restated by the oracle.  Bounded: one warm-up question, then questions until the budget."""
+    restated by the oracle.  Bounded: one warm-up question, a thread-count sweep of three questions per
+    setting (median decides), then questions until the budget."""
     from mmqg_amd.synthetic import build_models, synthetic_batch
     from oracle import mmqg_oracle as O
     vid, text, dec = build_models(w, "cpu", seed=0)
@@ -139,35 +227,46 @@ def cpu_baseline(w, budget_s):
         drop = dict(text=masks(w.ctx_len), dec=masks(w.tgt_len)) if p > 0 else None
         ot.step(b, training=True, drop=drop)
 
-    # pick the thread count that serves this small-op workload best (all cores oversubscribe it)
     one(0)
-    best, best_t, sweep = None, None, {}
-    for nt in sorted({1, 8, 16, 32, min(64, os.cpu_count() or 8)}):
-        if nt > (os.cpu_count() or 8):
+    ncpu = os.cpu_count() or 8
+    sweep, best_t, best = {}, 1, None
+    t_sweep0 = time.perf_counter()
+    for nt in (1, 8, 16):
+        if nt > ncpu:
             continue
         torch.set_num_threads(nt)
-        t0 = time.perf_counter()
-        one(1)
-        el = time.perf_counter() - t0
-        sweep[str(nt)] = round(1.0 / el, 3)
-        if best is None or el < best:
-            best, best_t = el, nt
+        times = []
+        for r in range(3):
+            t0 = time.perf_counter()
+            one(1 + r)
+            times.append(time.perf_counter() - t0)
+        med = sorted(times)[1]
+        sweep[str(nt)] = round(1.0 / med, 3)
+        if best is None or med < best:
+            best, best_t = med, nt
+        if time.perf_counter() - t_sweep0 > budget_s:      # a very large workload: stop sweeping
+            break
     torch.set_num_threads(best_t)
     n, t0 = 0, time.perf_counter()
     while True:
-        one(n + 2)
+        one(n + 4)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 64:
             break
     return {"value": round(n / el, 4), "unit": "questions/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} questions, batch 1, {w.name.split(':')[0]} shapes, fwd+bwd+3xAdam, torch-CPU oracle, "
-                      f"{el:.1f} s after warm-up; thread count chosen by a 1-question sweep over 1/8/16/32/64",
-            "host_cpus": os.cpu_count(), "one_question_sweep_qps_by_threads": sweep}
+                      f"{el:.1f} s after warm-up; thread count = best median of 3 questions each at 1/8/16 threads",
+            "host_cpus": ncpu, "sweep_qps_by_threads": sweep}
 
 
-def main():
-    a = parse()
+# -------------------------------------------------------------------------------------- main
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    a = parse(argv)
+    if self_launch_needed(a.gpus, os.environ):
+        sys.exit(self_launch(a, argv))
+
     import mmqg_amd  # noqa: F401
     from mmqg_amd.synthetic import WORKLOADS, build_models, synthetic_batch
     from mmqg_amd.trainer import BatchedTrainer
@@ -176,13 +275,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_pg = world > 1 or (os.environ.get("MMQG_FORCE_DP") == "1" and "RANK" in os.environ)
+    backend = None
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)
+        backend = f"{torch.distributed.get_backend()} (RCCL)"
+        if torch.distributed.get_world_size() != world:
+            raise SystemExit("process group size does not match WORLD_SIZE")
     w = WORKLOADS[a.workload]
     B = a.batch or w.batch
     vid, text, dec = build_models(w, dev, seed=0)          # same seed on every rank: identical replicas
@@ -220,7 +323,9 @@ def main():
                       "frame_dim": w.frame_dim, "audio_dim": w.audio_dim, "ctx_len": w.ctx_len, "tgt_len": w.tgt_len,
                       "vocab": w.vocab, "emb_dim": w.emb_dim, "hidden": w.hidden, "layers": w.layers,
                       "attn_widths": [w.text_max_length, w.av_max_length], "dropout": w.dropout,
-                      "parallelism": f"dp{world}", "hipgraph": bool(tr.use_graph)},
+                      "parallelism": f"dp{world}", "hipgraph": bool(tr.use_graph),
+                      "world_size": torch.distributed.get_world_size() if use_pg else 1,
+                      "collective_backend": backend},
            "final_loss": round(loss_val, 4)}
     if rank == 0:
         roof, mfma = kernel_rooflines(tr, w, a.kernel_iters)

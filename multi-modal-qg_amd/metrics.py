@@ -3,9 +3,11 @@ evaluate.py:101-116).
 
 ``sentence_bleu`` restates nltk.translate.bleu_score.sentence_bleu (nltk 3.x defaults: no
 smoothing function = method0, ``auto_reweigh=False``).  nltk is not installed in the build
-image, so this restatement is NOT pinned against nltk here; it follows the published
-algorithm (modified n-gram precision, closest-reference-length brevity penalty, zero precisions
-replaced by ``sys.float_info.min`` with a warning in nltk).  The reference calls it with the list
+image; the restatement follows the published algorithm (modified n-gram precision,
+closest-reference-length brevity penalty, zero precisions replaced by ``sys.float_info.min`` with
+a warning in nltk) and is pinned to the exact values nltk's own doctests publish
+(``sentence_bleu`` 0.5045666840058485 and 0.3920, ``corpus_bleu``'s 0.6223..., the
+``modified_precision`` fractions — tests/test_host_cpu.py).  The reference calls it with the list
 of reference WORDS as the list of references (train.py:115 passes ``question_str_list``), so each
 "reference" is a single word that is iterated character by character — ``reference_style=True``
 reproduces exactly that call; ``False`` computes standard single-reference sentence BLEU."""

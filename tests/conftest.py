@@ -16,3 +16,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Observed parity errors of every comparison made through golden_util.close (one line each:
+    what, max abs err, max|want|, relative, tolerance)."""
+    try:
+        import golden_util
+        golden_util.dump_parity_log(os.path.join(ROOT, "gpurun_out", "parity_errors.tsv"))
+    except Exception:
+        pass

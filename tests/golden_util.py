@@ -11,6 +11,37 @@ from oracle import mmqg_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+# Parity bar shared by every test file: max |got - want| <= tol * max|want|, i.e. RELATIVE to the expected
+# tensor's own magnitude (attention weights ~1/283 and small gradients are held to 1e-4 of themselves, not
+# of 1.0), with an absolute floor for tensors that are (near) zero.  Every comparison is logged so the
+# observed worst errors can be read back (gpurun_out/parity_errors.tsv on the GPU box).
+ABS_FLOOR = 1e-7
+PARITY_LOG = []
+
+
+def close(got, want, tol=1e-4, what="", floor=ABS_FLOOR):
+    got = torch.as_tensor(np.asarray(got) if not torch.is_tensor(got) else got).detach().double().cpu()
+    want = torch.as_tensor(np.asarray(want) if not torch.is_tensor(want) else want).detach().double().cpu()
+    assert got.shape == want.shape, (what, tuple(got.shape), tuple(want.shape))
+    if want.numel() == 0:
+        return
+    assert bool(torch.isfinite(got).all()), f"{what}: non-finite values"
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    allowed = max(tol * scale, floor)
+    PARITY_LOG.append((what, err, scale, err / scale if scale > 0 else 0.0, tol))
+    assert err <= allowed, f"{what}: max abs err {err:.3e} > {allowed:.3e} (tol {tol:g} x max|want| {scale:.3e})"
+
+
+def dump_parity_log(path):
+    if not PARITY_LOG:
+        return
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "a") as f:
+        for what, err, scale, rel, tol in PARITY_LOG:
+            f.write(f"{what}\t{err:.3e}\t{scale:.3e}\t{rel:.3e}\t{tol:g}\n")
+    PARITY_LOG.clear()
+
 
 def load_npz(name):
     return np.load(os.path.join(GOLDEN, name))

@@ -22,13 +22,7 @@ def mm():
     return _lib, ops
 
 
-def close(got, want, tol=TOL, what=""):
-    got = got.detach().double().cpu()
-    want = want.detach().double().cpu()
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    scale = max(1.0, float(want.abs().max())) if want.numel() else 1.0
-    err = float((got - want).abs().max()) if want.numel() else 0.0
-    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+from golden_util import close  # noqa: E402  (relative to max|want|, floor 1e-7, logged)
 
 
 def dev(t):

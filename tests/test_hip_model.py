@@ -30,13 +30,7 @@ def mm():
                 AudioVideoEncoder=AudioVideoEncoder, BatchedTrainer=BatchedTrainer)
 
 
-def close(got, want, tol=TOL, what=""):
-    got = torch.as_tensor(got).detach().double().cpu()
-    want = torch.as_tensor(np.asarray(want) if not torch.is_tensor(want) else want).detach().double().cpu()
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    scale = max(1.0, float(want.abs().max())) if want.numel() else 1.0
-    err = float((got - want).abs().max()) if want.numel() else 0.0
-    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+from golden_util import close  # noqa: E402,F811  (relative to max|want|, floor 1e-7, logged)
 
 
 def build_small(mm, z, prefix="init", dropout=0.0):

@@ -172,3 +172,53 @@ def test_bleu_restatement_known_values():
     s = reference_bleu_scores("what is a", ["a", "b"])
     assert s["bleu_1"] == pytest.approx(0.5) and 0.0 < s["bleu"] < 1e-50
     assert truncate_at_end([5, 7, 2, 9], 2) == [5, 7]
+
+
+def test_bleu_matches_the_values_nltk_publishes():
+    """nltk is absent here, but its docstrings publish exact results (nltk.translate.bleu_score:
+    sentence_bleu, corpus_bleu, modified_precision doctests); the restatement must hit them."""
+    from mmqg_amd.metrics import sentence_bleu
+    hyp1 = "It is a guide to action which ensures that the military always obeys the commands of the party".split()
+    hyp2 = "It is to insure the troops forever hearing the activity guidebook that party direct".split()
+    ref1 = "It is a guide to action that ensures that the military will forever heed Party commands".split()
+    ref2 = ("It is the guiding principle which guarantees the military forces always being under the command of the "
+            "Party").split()
+    ref3 = "It is the practical guide for the army always to heed the directions of the party".split()
+    refs = [ref1, ref2, ref3]
+    assert sentence_bleu(refs, hyp1) == pytest.approx(0.5045666840058485, rel=1e-12)        # sentence_bleu doctest
+    assert round(sentence_bleu(refs, hyp1, (1. / 5.,) * 5), 4) == 0.3920                      # custom-weights doctest
+    # corpus_bleu doctest: the average of the two sentence scores is 0.6223...
+    hyp_b = "he read the book because he was interested in world history".split()
+    ref_b = "he was interested in world history because he read the book".split()
+    assert (sentence_bleu(refs, hyp1) + sentence_bleu([ref_b], hyp_b)) / 2 == pytest.approx(0.6223247442490669, rel=1e-12)
+    # modified_precision doctests (unigram 17/18, bigram 10/17 for hyp1; 8/14 and 1/13 for hyp2), through the
+    # n-gram weights; hyp1 is as long as its closest reference, so its brevity penalty is 1
+    assert sentence_bleu(refs, hyp1, (1, 0, 0, 0)) == pytest.approx(0.9444444444444444, rel=1e-12)
+    assert sentence_bleu(refs, hyp1, (0, 1, 0, 0)) == pytest.approx(0.5882352941176471, rel=1e-12)
+    import math
+    bp2 = math.exp(1 - 16 / 14)                      # closest reference length to 14 words is 16
+    assert sentence_bleu(refs, hyp2, (1, 0, 0, 0)) == pytest.approx(bp2 * 0.5714285714285714, rel=1e-12)
+    assert sentence_bleu(refs, hyp2, (0, 1, 0, 0)) == pytest.approx(bp2 * 0.07692307692307693, rel=1e-12)
+    the7 = "the the the the the the the".split()
+    assert sentence_bleu(["the cat is on the mat".split(), "there is a cat on the mat".split()], the7,
+                         (1, 0, 0, 0)) == pytest.approx(0.2857142857142857, rel=1e-12)
+
+
+def test_bench_launches_itself_for_more_than_one_gpu(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE starts the one-node launcher as a child (VERDICT r1 #1)."""
+    import bench
+    assert bench.self_launch_needed(8, {}) and bench.self_launch_needed(2, {"RANK": "0"})
+    assert not bench.self_launch_needed(8, {"WORLD_SIZE": "8"}) and not bench.self_launch_needed(1, {})
+    argv = ["--gpus", "8", "--steps", "7", "--warmup", "2"]
+    cmd = bench.launcher_command(8, argv, 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                              # the ranks see the caller's own flags
+    assert 1024 < bench.free_port() < 65536
+    # on a box with fewer devices than asked for the parent says so and exits non-zero without spawning ranks
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 64" in r.stderr and "device(s)" in r.stderr

@@ -12,12 +12,7 @@ TOL = 1e-4
 torch.set_num_threads(4)
 
 
-def close(a, b, tol=TOL):
-    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = b.detach().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
-    assert a.shape == b.shape, (a.shape, b.shape)
-    err = np.max(np.abs(a - b)) if a.size else 0.0
-    assert err <= tol * max(1.0, float(np.max(np.abs(b))) if b.size else 1.0), f"max abs err {err}"
+from golden_util import close  # noqa: E402  (relative to max|want|, floor 1e-7, logged)
 
 
 def _grads(dec, text, vid):
