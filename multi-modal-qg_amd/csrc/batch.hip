@@ -2,7 +2,8 @@
 // the trainer's static input buffers: time-major frame features / raw frames, audio rows masked past
 // n_frames inside the fused value tensor (train.py:156 pads with zeros), time-major context / target ids,
 // the teacher-forcing decoder inputs (<start>, then target[t-1]: train.py:168,175), the per-row loss weights
-// (t < target_len) / B, and the three length vectors.  Replaces ~25 small framework kernels per step.
+// (t < target_len) / B, and the three length vectors, clamped to the static extents [0, Tc] / [0, Td] / [0, Tf]
+// (the BatchNorm frame counts and the masks downstream trust them).  Replaces ~25 small framework kernels per step.
 #include "mmqg_common.h"
 #include "mmqg_kernels.h"
 
@@ -20,7 +21,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(mmqg_batch_pack a, int6
     i -= n_frames_elems;
     if (i < n_audio) {                              // value rows of the audio modality, zero past n_frames
         const int j = (int)(i % a.Da), t = (int)((i / a.Da) % a.audio_rows), b = (int)(i / ((int64_t)a.Da * a.audio_rows));
-        const float v = t < a.n_frames[b] ? a.audio[i] : 0.f;
+        const float v = t < min(a.n_frames[b], a.Tf) ? a.audio[i] : 0.f;
         a.audio_out[(int64_t)b * a.audio_stride_b + (int64_t)t * a.Da + j] = v;
         return;
     }
@@ -40,9 +41,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(mmqg_batch_pack a, int6
     }
     i -= n_tgt;
     if (i < a.B) {
-        a.ctx_len_out[i] = a.ctx_len[i];
-        a.tgt_len_out[i] = a.tgt_len[i];
-        a.n_frames_out[i] = a.n_frames[i];
+        a.ctx_len_out[i] = min(max(a.ctx_len[i], 0), a.Tc);
+        a.tgt_len_out[i] = min(max(a.tgt_len[i], 0), a.Td);
+        a.n_frames_out[i] = min(max(a.n_frames[i], 0), a.Tf);
     }
 }
 

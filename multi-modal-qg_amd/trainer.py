@@ -43,7 +43,8 @@ def _round4(n: int) -> int:
 class BatchedTrainer:
     def __init__(self, av_enc_model, text_enc_model, dec_model, *, batch_size: int, n_frames: int, ctx_len: int,
                  tgt_len: int, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, start_id: int = 1,
-                 seed: int = 0, mask_mode: Optional[int] = None, process_group=None, use_graph: bool = False):
+                 seed: int = 0, mask_mode: Optional[int] = None, process_group=None, use_graph: bool = False,
+                 dropout_rank: Optional[int] = None):
         self.video = getattr(av_enc_model, "video_enc", av_enc_model)
         self.av_model, self.text, self.dec = av_enc_model, text_enc_model, dec_model
         dec = dec_model
@@ -71,9 +72,13 @@ class BatchedTrainer:
         self.start_id, self.seed = start_id, seed
         self.mask_mode = dec.mask_mode if mask_mode is None else mask_mode
         self.pg = process_group
-        self.world = 1
+        self.world, rank = 1, 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+            rank = torch.distributed.get_rank(process_group)
+        # every data-parallel rank draws its dropout masks from streams of its own (bits 48+ of the stream id):
+        # with one shared seed, local row b would otherwise get the identical mask on every rank
+        self.dropout_rank = rank if dropout_rank is None else int(dropout_rank)
         self.drop_text = float(self.text.dropout_p)
         self.drop_dec = float(dec.dropout_p)
         self.training = True
@@ -89,6 +94,7 @@ class BatchedTrainer:
         self._graph = None
         self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
         self._tr_jobs = None
+        self._audio_rows = 0
         self._side = torch.cuda.Stream(device=self.dev)
         self.chain_first = os.environ.get("MMQG_SIDE_FIRST", "0") != "1"
         if os.environ.get("MMQG_NO_AHEAD", "0") != "1":      # look-ahead recurrent products in the decoder's backward loop
@@ -229,7 +235,7 @@ class BatchedTrainer:
         dt.x, dt.ldx = w["xemb_c"].data_ptr(), self.E
         self._lstm_ptrs(dt, self.text.lstm.flat(), gt)
         dt.lens = w["ctx_len"].data_ptr()
-        dt.dropout_p, dt.seed, dt.stream_base = self.drop_text, self.seed, _TEXT_STREAM
+        dt.dropout_p, dt.seed, dt.stream_base = self.drop_text, self.seed, _TEXT_STREAM + (self.dropout_rank << 48)
         dt.seed_offset = self.step_dev.data_ptr()
         dt.gates, dt.hs, dt.cs, dt.hdrop = (w[k].data_ptr() for k in ("gates_t", "hs_t", "cs_t", "hdrop_t"))
         dt.y, dt.y_stride_t, dt.y_stride_b = vals.data_ptr(), H, self.val_stride
@@ -255,7 +261,7 @@ class BatchedTrainer:
         dd.w_attn, dd.b_attn = dec.text_attn.weight.data_ptr(), dec.text_attn.bias.data_ptr()
         self._lstm_ptrs(dd, dec.lstm.flat(), gd)
         dd.lens = w["tgt_len"].data_ptr()
-        dd.dropout_p, dd.seed, dd.stream_base = self.drop_dec, self.seed, _DEC_STREAM
+        dd.dropout_p, dd.seed, dd.stream_base = self.drop_dec, self.seed, _DEC_STREAM + (self.dropout_rank << 48)
         dd.seed_offset = self.step_dev.data_ptr()
         dd.scores, dd.attn, dd.ld_attn, dd.ctx = w["scores"].data_ptr(), w["attn"].data_ptr(), self.ldS, w["ctx"].data_ptr()
         dd.gates, dd.hs, dd.cs, dd.hdrop = (w[k].data_ptr() for k in ("gates_d", "hs_d", "cs_d", "hdrop_d"))
@@ -394,6 +400,12 @@ class BatchedTrainer:
                            row_w=w["row_w"].data_ptr(), ctx_len_out=w["ctx_len"].data_ptr(),
                            tgt_len_out=w["tgt_len"].data_ptr(), n_frames_out=w["n_frames"].data_ptr())
         check(_lib.load().mmqg_pack_batch(C.byref(p), ops._stream()), "pack_batch")
+        # the pack kernel writes audio rows [0, audio.shape[1]); rows a previous, longer batch left behind are
+        # padding now (train.py:156 pads with zeros) and the no-op masks attend every row
+        rows = audio.shape[1]
+        if rows < self._audio_rows:
+            w["values"][:, self.off_audio + rows * self.Da:self.off_audio + self._audio_rows * self.Da].zero_()
+        self._audio_rows = rows
         # the gradient of the frame LSTM's input is only needed when a CNN produced that input
         self.g_vid.dx = w["dfeats"].data_ptr() if self._cnn_on else None
 
@@ -442,8 +454,9 @@ class BatchedTrainer:
             ops.embedding_fwd(emb, w["ids_d"], w["xemb_d"].view(-1, self.E))
             self.d_dec.phase = 1
             check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd(hoists)")
-            if training:
-                self._refresh_transposes()
+            # always: a backward may follow an eval-mode forward too (tr.eval(); tr.forward_backward(batch)), and
+            # its fused loops read the k-major copies
+            self._refresh_transposes()
 
         def chain():
             s = ops._stream()
@@ -737,6 +750,8 @@ class BatchedTrainer:
         check(lib.mmqg_decoder_decode_run(C.byref(d), s), "decoder_decode_run")
         return dict(ids=ids[1:].t().contiguous(), attn=attn[:, :, :self.S],
                     loss=loss_rows.sum() if with_loss else None, logits=logits if keep_logits else None,
+                    # per-question sum of the step losses (train.py:104-106 before the division by target_len)
+                    loss_per_question=(loss_rows * B).sum(0) if with_loss else None,
                     hidden=(hs[T % 2], cs[T % 2]))
 
     @torch.no_grad()

@@ -236,7 +236,78 @@ def make_default_dims():
     print("default_dims.npz:", len(out), "arrays")
 
 
+def _ref_file_module(name, rel):
+    """A reference source file imported from where it lies (the build repo has a ``utils`` package of the
+    same name, so the file is loaded by path instead of through ``import utils``)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def make_data_layer():
+    """The reference's data layer on a tiny corpus (utils/dataset.py:8-55, utils/custom_transforms.py:6-44):
+    the corpus itself (split / vocab / index_to_word JSON text, uint8 frame arrays) and, for every question,
+    the 8-tuple ``VQGDataset.__getitem__`` returns under two transform stacks — train.py:229's
+    [ToFloatTensor, Resize(int)] and evaluate.py:163's [ToFloatTensor, Resize((h,w)), Normalize]."""
+    import json
+    import tempfile
+    ds_mod = _ref_file_module("ref_utils_dataset", "utils/dataset.py")
+    tf = _ref_file_module("ref_utils_custom_transforms", "utils/custom_transforms.py")
+
+    class Stack:                      # torchvision.transforms.Compose is what train.py:229 uses; it is absent here
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    words = ["<pad>", "<start>", "<end>", "what", "is", "the", "cat", "doing", "a", "sits", "on", "mat", "why", "dog",
+             "runs", "fast"]
+    vocab = {w: i for i, w in enumerate(words)}
+    qs = [{"video_id": "abc", "question_id": 7, "context": "the cat sits on a mat", "question": "what is the cat doing"},
+          {"video_id": "d-9", "question_id": 12, "context": "a dog runs", "question": "why is the dog fast"},
+          {"video_id": "abc", "question_id": 3, "context": "a cat", "question": "what is a cat"}]
+    shapes = [(3, 20, 24), (2, 30, 18), (4, 16, 16)]       # (T, H, W): landscape, portrait, square
+    rng = np.random.default_rng(20260203)
+    out = {"json/questions": np.array(json.dumps(qs)), "json/vocab": np.array(json.dumps(vocab)),
+           "json/index_to_word": np.array(json.dumps({str(i): w for w, i in vocab.items()})),
+           "cfg/resize_int": np.array(14), "cfg/resize_hw": np.array([12, 10]),
+           "cfg/mean": np.array([0.43216, 0.394666, 0.37645], dtype=np.float32),      # config.py vid_mean / vid_std
+           "cfg/std": np.array([0.22803, 0.22145, 0.216989], dtype=np.float32)}
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "frames")); os.makedirs(os.path.join(d, "audio"))
+        for i, (q, (T, hh, ww)) in enumerate(zip(qs, shapes)):
+            arr = rng.integers(0, 256, (T, hh, ww, 3), dtype=np.uint8)
+            out[f"raw/{i}/frames"] = arr
+            np.save(os.path.join(d, "frames", f"v_{q['video_id']}_q_{q['question_id']}_.npy"), arr)
+        for name, obj in (("q.json", qs), ("vocab.json", vocab), ("itow.json", {str(i): w for w, i in vocab.items()})):
+            json.dump(obj, open(os.path.join(d, name), "w"))
+        stacks = {"train": Stack([tf.ToFloatTensor(), tf.Resize(int(out["cfg/resize_int"]))]),
+                  "eval": Stack([tf.ToFloatTensor(), tf.Resize(tuple(int(v) for v in out["cfg/resize_hw"])),
+                                 tf.Normalize(out["cfg/mean"].tolist(), out["cfg/std"].tolist())])}
+        for sname, stack in stacks.items():
+            ds = ds_mod.VQGDataset(os.path.join(d, "q.json"), os.path.join(d, "vocab.json"), os.path.join(d, "itow.json"),
+                                   os.path.join(d, "frames"), os.path.join(d, "audio"), tf.prepare_sequence, stack)
+            out[f"{sname}/len"] = np.array(len(ds))
+            for i in range(len(ds)):
+                frames, audio_file, ctx, qid, qstr, tgt, cl, tl = ds[i]
+                out[f"{sname}/{i}/frames"] = frames.numpy()
+                out[f"{sname}/{i}/audio_file"] = np.array(os.path.relpath(audio_file, d))
+                out[f"{sname}/{i}/context"] = ctx.numpy()
+                out[f"{sname}/{i}/question_id"] = np.array(qid)
+                out[f"{sname}/{i}/question"] = np.array(qstr)
+                out[f"{sname}/{i}/target"] = tgt.numpy()
+                out[f"{sname}/{i}/lens"] = np.array([cl, tl])
+    np.savez_compressed(os.path.join(HERE, "data_layer.npz"), **out)
+    print("data_layer.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     make_small()
     make_default_dims()
     make_plain_decoder()
+    make_data_layer()

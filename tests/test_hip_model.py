@@ -107,6 +107,34 @@ def test_dropin_modules_match_reference_forward_and_backward(mm):
                 close(p.grad, z[f"train/{b}/grad/{name}/{k}"], what=f"grad {name}/{k}")
 
 
+def test_audio_video_encoder_forward_matches_reference(mm):
+    """AudioVideoEncoder.forward(audio, frames) (encoder.py:121-131) + the caller's zero padding to
+    av_max_length rows (train.py:155-157) against the reference's frame encoder output.  Audio: the VGGish
+    front-end cannot be loaded offline, so ``audio_file`` is the (n_clips, audio_emb_dim) feature tensor and
+    comes back as rows — the decoder's contract (decoder.py:95 bmm) — not as the reference's single
+    flattened row (encoder.py:123), which only works for one clip."""
+    z = load_npz("small_model.npz")
+    c, _ = small_cfg(z)
+    av = mm["AudioVideoEncoder"](3, 3, 1, c["Dv"], c["flatten"])
+    av.video_enc.load_state_dict(state_from(z, "init/vid"))
+    av = av.cuda().train()
+    init = {k: v.clone() for k, v in av.state_dict().items()}
+    assert all(k.startswith("video_enc.") for k in init)                 # no audio parameters: pass-through
+    for b, s in enumerate(small_samples(z)):
+        av.load_state_dict(init)                                         # BatchNorm running stats as in the fixture
+        audio, frames = s["audio"].cuda(), s["frames"].cuda()
+        audio_emb, video_emb = av(audio, frames.unsqueeze(0))
+        n_frames = video_emb.shape[0]
+        assert n_frames == frames.shape[1] and tuple(video_emb.shape) == (n_frames, c["Dv"])
+        assert tuple(audio_emb.shape) == (audio.shape[0], c["Da"]) and torch.equal(audio_emb, audio)
+        pad_audio = F.pad(audio_emb, (0, 0, 0, c["Lav"] - n_frames))    # train.py:156
+        pad_video = F.pad(video_emb, (0, 0, 0, c["Lav"] - n_frames))    # train.py:157
+        assert tuple(pad_audio.shape) == (c["Lav"], c["Da"])
+        close(pad_video, z[f"train/{b}/video_emb"], what=f"AudioVideoEncoder video_emb {b}")
+    with pytest.raises(RuntimeError):
+        av("clip.wav", frames.unsqueeze(0))                              # a wav path needs the remote VGGish
+
+
 def test_dropin_modules_train_with_torch_adam_like_train_py(mm):
     """The reference's optimizer setup verbatim (three torch Adam instances, shared embedding in
     two of them) on the drop-in modules: weights after two iterations match the reference's."""
@@ -324,14 +352,24 @@ def test_full_size_step_matches_oracle(mm, name, B):
     _check_step_against_oracle(mm, w, batch, B, w.dropout, 0, tol=2e-4, wtol=5e-6, well_conditioned_only=True)
 
 
-def _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode, tol=TOL, wtol=2e-6, well_conditioned_only=False):
+def test_eval_mode_forward_then_backward_gives_the_same_gradients(mm):
+    """tr.eval(); tr.forward_backward(batch) at H=512, where the fused backward loops read the k-major
+    weight copies: they must be rebuilt by an eval-mode forward too."""
+    from mmqg_amd.synthetic import WORKLOADS, synthetic_batch
+    w = WORKLOADS["config2"]
+    batch = synthetic_batch(w, seed=5, batch=3, ragged=True)
+    _check_step_against_oracle(mm, w, batch, 3, 0.0, 0, tol=2e-4, wtol=5e-6, well_conditioned_only=True, eval_mode=True)
+
+
+def _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode, tol=TOL, wtol=2e-6, well_conditioned_only=False,
+                               eval_mode=False):
     from mmqg_amd import ops
     from mmqg_amd.synthetic import build_models
     from mmqg_amd.trainer import _DEC_STREAM, _TEXT_STREAM
     from oracle import mmqg_oracle as O
     vid, text, dec = build_models(w, "cuda", seed=1)
     dec.mask_mode = mask_mode
-    tr = _trainer(mm, vid, text, dec, batch, seed=77).train()
+    tr = _trainer(mm, vid, text, dec, batch, seed=77).train(not eval_mode)
     sd = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in (dec, text, vid)]
     sd[1]["word_embeddings.weight"] = sd[0]["emb_layer.weight"]
     cfg = dict(num_layers=w.layers, hidden_dim=w.hidden, text_max_length=w.text_max_length,
@@ -346,7 +384,7 @@ def _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode, tol=TOL, wto
         drop = dict(text=masks(_TEXT_STREAM, w.ctx_len), dec=masks(_DEC_STREAM, w.tgt_len))
     ot = O.OracleTrainer(sd[0], sd[1], sd[2], cfg, lr=1e-4)
     want_loss, want_logits = ot.step({k: (v.long() if v.dtype == torch.int32 else v) for k, v in batch.items()},
-                                     training=True, drop=drop)
+                                     training=not eval_mode, drop=drop)
     grads = {id(t): t.grad.clone() for t in ot.trainable() if t.grad is not None}
     loss = tr.forward_backward(batch)
     close(loss.view(()), np.float32(want_loss), tol=tol, what="loss")
@@ -381,7 +419,7 @@ def test_graph_replay_equals_eager_steps(mm):
 
 
 # ------------------------------------------------------------------ data parallel on the GPU
-def _dp_worker(rank, world, port, use_graph, q):
+def _dp_worker(rank, world, port, use_graph, q, dropout=0.0, steps=2):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -397,12 +435,13 @@ def _dp_worker(rank, world, port, use_graph, q):
     from mmqg_amd.distributed import shard_batch
     from mmqg_amd.synthetic import build_models
     from mmqg_amd.trainer import BatchedTrainer
-    w, full = _oracle_setup(4, 21, 0.0, True)
+    w, full = _oracle_setup(4, 21, dropout, True)
     vid, text, dec = build_models(w, "cuda", seed=3)
     shard = shard_batch(full, rank, world)
     tr = BatchedTrainer(vid, text, dec, batch_size=2, n_frames=w.n_frames, ctx_len=w.ctx_len, tgt_len=w.tgt_len,
-                        use_graph=use_graph).train()
-    for _ in range(2):
+                        use_graph=use_graph, seed=31).train()
+    assert tr.dropout_rank == rank
+    for _ in range(steps):
         tr.step(shard)
     torch.cuda.synchronize()
     q.put((rank, tr.flat_p.cpu().numpy()))      # by value: the worker may exit before the parent reads
@@ -410,17 +449,15 @@ def _dp_worker(rank, world, port, use_graph, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_two_rank_data_parallel_step_equals_single_rank_full_batch(mm, use_graph):
+def _run_two_ranks(use_graph, dropout=0.0, steps=2):
     import socket
     import torch.multiprocessing as mp
-    from mmqg_amd.synthetic import build_models
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, use_graph, q, dropout, steps)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(2))
@@ -429,9 +466,43 @@ def test_two_rank_data_parallel_step_equals_single_rank_full_batch(mm, use_graph
         assert p.exitcode == 0
     res = {k: torch.from_numpy(v) for k, v in res.items()}
     assert torch.equal(res[0], res[1]), "replicas diverged"
+    return res
+
+
+def test_two_rank_data_parallel_with_dropout_draws_rank_specific_masks(mm):
+    """Dropout 0.25 live under data parallelism: every rank draws from dropout streams of its own
+    (``dropout_rank``), so the exchanged gradient is the mean of two single-rank passes that use rank 0's and
+    rank 1's streams on their shards — and NOT what two ranks sharing one stream would give."""
+    from mmqg_amd.distributed import shard_batch
+    from mmqg_amd.synthetic import build_models
+    res = _run_two_ranks(True, dropout=0.25, steps=1)
+    w, full = _oracle_setup(4, 21, 0.25, True)
+
+    def single(rank_streams):
+        grads, tr0 = [], None
+        for r in range(2):
+            vid, text, dec = build_models(w, "cuda", seed=3)
+            shard = shard_batch(full, r, 2)
+            tr = mm["BatchedTrainer"](vid, text, dec, batch_size=2, n_frames=w.n_frames, ctx_len=w.ctx_len,
+                                      tgt_len=w.tgt_len, seed=31, dropout_rank=rank_streams[r]).train()
+            tr.forward_backward(shard)
+            grads.append(tr.flat_g.clone())
+            tr0 = tr0 or tr
+        tr0.flat_g.copy_((grads[0] + grads[1]) / 2)
+        tr0._adam()
+        return tr0.flat_p.detach().cpu()
+    close(res[0], single((0, 1)), tol=2e-6, what="2-rank DP weights with dropout vs rank-specific single-rank passes")
+    shared = single((0, 0))                                   # what identical masks on both ranks would have produced
+    assert float((res[0] - shared).abs().max()) > 1e-5
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_rank_data_parallel_step_equals_single_rank_full_batch(mm, use_graph):
+    from mmqg_amd.synthetic import build_models
+    res = _run_two_ranks(use_graph)
     w, full = _oracle_setup(4, 21, 0.0, True)
     vid, text, dec = build_models(w, "cuda", seed=3)
-    tr = _trainer(mm, vid, text, dec, full).train()
+    tr = _trainer(mm, vid, text, dec, full, seed=31).train()
     for _ in range(2):
         tr.step(full)
     close(res[0], tr.flat_p, tol=2e-6, what="2-rank DP weights vs single-rank full batch")

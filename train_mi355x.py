@@ -95,35 +95,67 @@ def run_real(a, world, rank, dev):
                         start_id=train_ds.vocab["<start>"], seed=a.seed)
     end_id = train_ds.vocab["<end>"]
 
-    def batches(ds, shuffle, epoch):
-        order = np.random.default_rng(a.seed + epoch).permutation(len(ds)) if shuffle else np.arange(len(ds))
+    def train_batches(epoch):
+        order = np.random.default_rng(a.seed + epoch).permutation(len(train_ds))
         gb = B * world
         for i in range(0, len(order) - gb + 1, gb):                               # drop the ragged tail
             idx = order[i:i + gb][rank * B:(rank + 1) * B]
-            yield collate_questions([ds[j] for j in idx], [ds.audio_features(j) for j in idx], Tf, Tc, Td, cfg.audio_emb)
+            yield collate_questions([train_ds[j] for j in idx], [train_ds.audio_features(j) for j in idx], Tf, Tc, Td,
+                                    cfg.audio_emb)
+
+    def val_batches():
+        """Every validation question exactly once over all ranks: rank r takes questions r, r+world, ...;
+        a short last batch is padded by repeating its last question and the copies are ignored."""
+        mine = list(range(rank, len(val_ds), world))
+        for i in range(0, len(mine), B):
+            idx = mine[i:i + B]
+            pad = idx + [idx[-1]] * (B - len(idx))
+            yield len(idx), collate_questions([val_ds[j] for j in pad], [val_ds.audio_features(j) for j in pad], Tf, Tc,
+                                              Td, cfg.audio_emb)
+
+    def all_sum(vals):
+        t = torch.tensor(vals, device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t)
+        return t.tolist()
+
+    def sync_bn_buffers():
+        """BatchNorm running statistics advance on every rank's own shard; checkpoints hold their mean."""
+        if world > 1:
+            for name, buf in av.named_buffers():
+                if buf.is_floating_point():
+                    torch.distributed.all_reduce(buf)
+                    buf.div_(world)
 
     best = float("inf")
+    bleu_keys = ("bleu", "bleu_1", "bleu_2", "bleu_3")
     for epoch in range(cfg.epochs if a.epochs is None else a.epochs):
         tr.train()
         tot, n = 0.0, 0
-        for batch in batches(train_ds, True, epoch):
+        for batch in train_batches(epoch):
             loss = tr.step({k: v for k, v in batch.items() if torch.is_tensor(v)})
             tot += float(loss) / max(1.0, float(batch["tgt_len"].float().mean())); n += 1
         tr.eval()
-        vloss, bleu, m = 0.0, {"bleu": 0.0, "bleu_1": 0.0, "bleu_2": 0.0, "bleu_3": 0.0}, 0
-        for batch in batches(val_ds, False, 0):
+        sync_bn_buffers()
+        # validate() (train.py:61-129): per question loss / target_len and the four BLEU numbers, averaged over
+        # the questions of the whole validation set (all ranks)
+        vloss, bleu, m = 0.0, dict.fromkeys(bleu_keys, 0.0), 0
+        for valid, batch in val_batches():
             out = tr.decode({k: v for k, v in batch.items() if torch.is_tensor(v)}, with_loss=True)
-            vloss += float(out["loss"]) / max(1.0, float(batch["tgt_len"].float().mean())); m += 1
-            for b, q in enumerate(batch["question"]):
+            per_q = (out["loss_per_question"].cpu() / batch["tgt_len"].float().clamp(min=1))[:valid]
+            vloss += float(per_q.sum()); m += valid
+            for b in range(valid):
                 pred = ids_to_words(truncate_at_end(out["ids"][b].tolist(), end_id), val_ds.index_to_word)
-                for k, v in reference_bleu_scores(q, pred).items():
-                    bleu[k] += v / B
+                for k, v in reference_bleu_scores(batch["question"][b], pred).items():
+                    bleu[k] += v
+        tot, n, vloss, m, *bl = all_sum([tot, n, vloss, m] + [bleu[k] for k in bleu_keys])
+        val_loss = vloss / max(m, 1.0)
         if rank == 0:
-            stats = {"epoch": epoch, "train_loss": tot / max(n, 1), "val_loss": vloss / max(m, 1),
-                     **{k: v / max(m, 1) for k, v in bleu.items()}}
+            stats = {"epoch": epoch, "train_loss": tot / max(n, 1.0), "val_loss": val_loss,
+                     **{k: v / max(m, 1.0) for k, v in zip(bleu_keys, bl)}}
             print(json.dumps(stats), flush=True)
-            if m and vloss / m < best:                                            # train.py:198-206
-                best = vloss / m
+            if m and val_loss < best:                                             # train.py:198-206
+                best = val_loss
                 save_models(cfg, av, text, dec)
             save_models(cfg, av, text, dec, last=True)                            # train.py:209-214
             save_training_state(cfg.output_path / "training_state.pt", tr, epoch=epoch)
