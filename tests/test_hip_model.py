@@ -347,9 +347,12 @@ def test_full_size_step_matches_oracle(mm, name, B):
     from mmqg_amd.synthetic import WORKLOADS, synthetic_batch
     w = WORKLOADS[name]
     batch = synthetic_batch(w, seed=11, batch=B, ragged=True)
-    # first Adam step = lr*g/(|g|+eps): ill-conditioned where |g| ~ eps, so the tight bound is applied to the
-    # elements whose gradient is not tiny (and twice the 1e-4 step size bounds the rest)
-    _check_step_against_oracle(mm, w, batch, B, w.dropout, 0, tol=2e-4, wtol=5e-6, well_conditioned_only=True)
+    # loss and every gradient: north_star's 1e-4, relative to each tensor's own magnitude (observed <= 7.3e-5, the
+    # worst being a conv weight gradient of magnitude 1e-4; most are < 1e-5: gpurun_out/parity_errors.tsv).
+    # Weights after the first Adam step = lr*g/(|g|+eps), which is ill-conditioned where |g| ~ eps = 1e-8: the
+    # tight bound (5e-6 of the tensor's magnitude) is applied to the elements whose gradient is not tiny; for
+    # the rest the only statement that holds by construction is |difference| <= 2*lr (each side moved <= lr).
+    _check_step_against_oracle(mm, w, batch, B, w.dropout, 0, tol=1e-4, wtol=5e-6, well_conditioned_only=True)
 
 
 def test_eval_mode_forward_then_backward_gives_the_same_gradients(mm):
@@ -358,7 +361,7 @@ def test_eval_mode_forward_then_backward_gives_the_same_gradients(mm):
     from mmqg_amd.synthetic import WORKLOADS, synthetic_batch
     w = WORKLOADS["config2"]
     batch = synthetic_batch(w, seed=5, batch=3, ragged=True)
-    _check_step_against_oracle(mm, w, batch, 3, 0.0, 0, tol=2e-4, wtol=5e-6, well_conditioned_only=True, eval_mode=True)
+    _check_step_against_oracle(mm, w, batch, 3, 0.0, 0, tol=1e-4, wtol=5e-6, well_conditioned_only=True, eval_mode=True)
 
 
 def _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode, tol=TOL, wtol=2e-6, well_conditioned_only=False,
@@ -399,7 +402,8 @@ def _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode, tol=TOL, wto
                 g = grads[id(osd[k])]
                 keep = g.abs() > 1e-3 * g.abs().max()
                 close(p.detach().cpu()[keep], osd[k][keep], tol=wtol, what=f"weight {k} after Adam (|g| not tiny)")
-                close(p, osd[k], tol=2e-4, what=f"weight {k} after Adam")
+                worst = float((p.detach().cpu() - osd[k]).abs().max())
+                assert worst <= 2.002e-4, f"weight {k} after Adam: {worst:.3e} exceeds two Adam steps of lr = 1e-4"
             else:
                 close(p, osd[k], tol=wtol, what=f"weight {k} after Adam")
 
