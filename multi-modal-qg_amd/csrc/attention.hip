@@ -81,7 +81,7 @@ struct AttnFwdK {
     const float* scores; int ld_s;
     float* attn; int ld_a;
     float* ctx; int ld_c;
-    int chunks_text, chunks_audio;   // chunk index boundaries (video chunks follow)
+    int chunks_text, chunks_audio, chunks_video;   // column chunks per question and modality
     int vec_text, vec_audio, vec_video;
 };
 
@@ -92,10 +92,21 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
     __shared__ __attribute__((aligned(16))) float red[kGroups * kChunk];
     __shared__ float sh[8];
 
-    const int b = blockIdx.y;
-    int chunk = blockIdx.x, modality = 0;
-    if (chunk >= a.chunks_text) { chunk -= a.chunks_text; modality = 1; }
-    if (modality == 1 && chunk >= a.chunks_audio) { chunk -= a.chunks_audio; modality = 2; }
+    // Work items in dispatch order: every text item of the batch first (Lt rows each: the heavy ones), then the
+    // audio / video items (Lav rows).  Workgroups are handed to the CUs in launch order, so issuing the heavy
+    // items first spreads them evenly (2 per CU at config 2) and the light ones fill in behind them; with the
+    // natural (question, modality, chunk) order some CUs drew 3 heavy + 2 light items, 27% above the mean, and
+    // every CU streams at about the same rate (MI355X_MICROARCH.md: ~10 B/clk/CU from HBM).
+    int n = blockIdx.x, modality = 0, b, chunk;
+    const int text_items = a.v.B * a.chunks_text;
+    if (n < text_items) {
+        b = n / a.chunks_text; chunk = n - b * a.chunks_text;
+    } else {
+        n -= text_items;
+        const int per_q = a.chunks_audio + a.chunks_video;
+        b = n / per_q; chunk = n - b * per_q; modality = 1;
+        if (chunk >= a.chunks_audio) { chunk -= a.chunks_audio; modality = 2; }
+    }
     const Segment sg = pick_segment(a.v, modality, b);
     const bool vec = modality == 0 ? a.vec_text : (modality == 1 ? a.vec_audio : a.vec_video);
     const int tid = threadIdx.x;
@@ -106,15 +117,24 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
     const int col = chunk * kChunk + 4 * cl;
     const bool col_ok = col < sg.D;
     const float* V = sg.base + col;
-    // The first four rows are requested BEFORE the softmax so their HBM latency hides behind it
-    // (a launch is ~10 us: the fixed prologue matters as much as the streaming rate).
-    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
-    const int i0 = rg, i1 = rg + kGroups, i2 = rg + 2 * kGroups, i3 = rg + 3 * kGroups;
-    if (vec && col_ok) {
-        if (i0 < sg.L) p0 = *reinterpret_cast<const float4*>(V + (int64_t)i0 * sg.D);
-        if (i1 < sg.L) p1 = *reinterpret_cast<const float4*>(V + (int64_t)i1 * sg.D);
-        if (i2 < sg.L) p2 = *reinterpret_cast<const float4*>(V + (int64_t)i2 * sg.D);
-        if (i3 < sg.L) p3 = *reinterpret_cast<const float4*>(V + (int64_t)i3 * sg.D);
+    // Rows go through the registers in batches of kU per thread (rows rg, rg+kGroups, ...), two batches in
+    // flight: the first two are requested BEFORE the softmax so their HBM latency hides behind it (a launch is
+    // ~10 us: the fixed prologue matters as much as the streaming rate).  Row indices past the segment are
+    // clamped to its last row and get weight 0, so EVERY batch — the ragged last one too — is kU independent
+    // loads; single-row tail iterations would each expose one full memory latency (two or three per thread at
+    // 283 / 101 rows).
+    constexpr int kU = 4;
+    float4 cur[kU], nxt[kU];
+    const int last_row = sg.L - 1, row_len = sg.D;
+    auto fetch = [V, last_row, row_len](float4 (&dst)[kU], int first) {     // (captures by value: no struct reference)
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            dst[u] = *reinterpret_cast<const float4*>(V + (int64_t)min(first + u * kGroups, last_row) * row_len);
+    };
+    const bool stream = vec && col_ok;
+    if (stream) {
+        fetch(cur, rg);
+        fetch(nxt, rg + kU * kGroups);
     }
 
     // ---- softmax of the score segment (every chunk of the segment recomputes it; L <= a few hundred).
@@ -151,30 +171,22 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
     if (col_ok) {
         if (vec) {
-            {
-                const float w0 = i0 < sg.L ? w[i0] : 0.f, w1 = i1 < sg.L ? w[i1] : 0.f;
-                const float w2 = i2 < sg.L ? w[i2] : 0.f, w3 = i3 < sg.L ? w[i3] : 0.f;
-                acc0.x += w0 * p0.x; acc0.y += w0 * p0.y; acc0.z += w0 * p0.z; acc0.w += w0 * p0.w;
-                acc1.x += w1 * p1.x; acc1.y += w1 * p1.y; acc1.z += w1 * p1.z; acc1.w += w1 * p1.w;
-                acc0.x += w2 * p2.x; acc0.y += w2 * p2.y; acc0.z += w2 * p2.z; acc0.w += w2 * p2.w;
-                acc1.x += w3 * p3.x; acc1.y += w3 * p3.y; acc1.z += w3 * p3.z; acc1.w += w3 * p3.w;
-            }
-            int i = rg + 4 * kGroups;
-            for (; i + 3 * kGroups < sg.L; i += 4 * kGroups) {
-                const float4 x0 = *reinterpret_cast<const float4*>(V + (int64_t)(i) * sg.D);
-                const float4 x1 = *reinterpret_cast<const float4*>(V + (int64_t)(i + kGroups) * sg.D);
-                const float4 x2 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 2 * kGroups) * sg.D);
-                const float4 x3 = *reinterpret_cast<const float4*>(V + (int64_t)(i + 3 * kGroups) * sg.D);
-                const float w0 = w[i], w1 = w[i + kGroups], w2 = w[i + 2 * kGroups], w3 = w[i + 3 * kGroups];
-                acc0.x += w0 * x0.x; acc0.y += w0 * x0.y; acc0.z += w0 * x0.z; acc0.w += w0 * x0.w;
-                acc1.x += w1 * x1.x; acc1.y += w1 * x1.y; acc1.z += w1 * x1.z; acc1.w += w1 * x1.w;
-                acc0.x += w2 * x2.x; acc0.y += w2 * x2.y; acc0.z += w2 * x2.z; acc0.w += w2 * x2.w;
-                acc1.x += w3 * x3.x; acc1.y += w3 * x3.y; acc1.z += w3 * x3.z; acc1.w += w3 * x3.w;
-            }
-            for (; i < sg.L; i += kGroups) {
-                const float4 x0 = *reinterpret_cast<const float4*>(V + (int64_t)i * sg.D);
-                const float w0 = w[i];
-                acc0.x += w0 * x0.x; acc0.y += w0 * x0.y; acc0.z += w0 * x0.z; acc0.w += w0 * x0.w;
+            for (int base = rg; base < sg.L; base += kU * kGroups) {
+                float wv[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const int i = base + u * kGroups;
+                    wv[u] = i < sg.L ? w[i] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < kU; u += 2) {
+                    acc0.x += wv[u] * cur[u].x; acc0.y += wv[u] * cur[u].y; acc0.z += wv[u] * cur[u].z; acc0.w += wv[u] * cur[u].w;
+                    acc1.x += wv[u + 1] * cur[u + 1].x; acc1.y += wv[u + 1] * cur[u + 1].y;
+                    acc1.z += wv[u + 1] * cur[u + 1].z; acc1.w += wv[u + 1] * cur[u + 1].w;
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) cur[u] = nxt[u];
+                if (base + 2 * kU * kGroups < sg.L) fetch(nxt, base + 2 * kU * kGroups);
             }
         } else {
             for (int i = rg; i < sg.L; i += kGroups) {
@@ -344,12 +356,13 @@ int attn_softmax_context_fwd(const mmqg_attn_values& v, const float* scores, int
     static const int chunk = [] { const char* e = getenv("MMQG_ATTN_CHUNK"); return e ? atoi(e) : 64; }();
     k.chunks_text = ceil_div(v.H, chunk);
     k.chunks_audio = ceil_div(v.Da, chunk);
-    const int chunks_video = ceil_div(v.Dv, chunk);
+    k.chunks_video = ceil_div(v.Dv, chunk);
     k.vec_text = vec_ok(v.text, v.text_stride_b, v.H);
     k.vec_audio = vec_ok(v.audio, v.audio_stride_b, v.Da);
     k.vec_video = vec_ok(v.video, v.video_stride_b, v.Dv);
-    dim3 grid(k.chunks_text + k.chunks_audio + chunks_video, v.B);
+    dim3 grid((unsigned)((k.chunks_text + k.chunks_audio + k.chunks_video) * v.B));
     if (chunk == 64) hipLaunchKernelGGL(attn_softmax_context_fwd_kernel<64>, grid, dim3(256), 0, s, k);
+    else if (chunk == 32) hipLaunchKernelGGL(attn_softmax_context_fwd_kernel<32>, grid, dim3(256), 0, s, k);
     else if (chunk == 256) hipLaunchKernelGGL(attn_softmax_context_fwd_kernel<256>, grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL(attn_softmax_context_fwd_kernel<128>, grid, dim3(256), 0, s, k);
     return check_launch("attn_softmax_context_fwd");
