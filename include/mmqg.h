@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMQG_ABI_VERSION 2
+#define MMQG_ABI_VERSION 3
 #define MMQG_MAX_LAYERS 8
 
 typedef void* mmqg_stream; /* hipStream_t */
@@ -180,6 +180,16 @@ typedef struct {
     float* hs; float* cs;                           /* [L][T+1][B][H]; slot 0 = initial state */
     float* hdrop;                                   /* [L-1][T][B][H], NULL if no dropout */
     float* y; int64_t y_stride_t; int64_t y_stride_b; /* optional top-layer outputs (0 past lens) */
+    float* persist_ws; int64_t persist_ws_bytes;    /* optional workspace (16-byte aligned, size from
+                                                       mmqg_lstm_seq_persist_ws_bytes): with it, and a shape the
+                                                       persistent kernel takes, the whole forward time loop is ONE
+                                                       launch whose workgroups keep the recurrent weights in LDS and
+                                                       meet at a device-wide barrier per wavefront diagonal.  The
+                                                       caller must not have TWO such launches in flight on one device
+                                                       (two streams, two processes): each could end up half resident
+                                                       and wait for workgroups the other one keeps off the CUs; the
+                                                       barrier's spins are bounded (seconds) and then poison hs with
+                                                       NaN instead of hanging */
 } mmqg_lstm_seq;
 
 typedef struct {
@@ -200,6 +210,15 @@ typedef struct {
 } mmqg_lstm_seq_grad;
 
 int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream);
+/* bytes of persist_ws the persistent forward needs for this shape; 0 = shape not taken (B > 64, H < 128 or not a
+ * multiple of 16, ...): the forward then runs one launch per wavefront diagonal */
+int64_t mmqg_lstm_seq_persist_ws_bytes(int T, int B, int L, int H);
+/* diagnostics: how many forward time loops this process has run as persistent launches so far */
+int mmqg_persist_launch_count(void);
+/* diagnostics: the following persistent launches write 4 wall-clock stamps (100 MHz) per (workgroup, diagonal) into
+ * buf[words] (start, products done, cell done, barrier passed); NULL switches it off.  Stamped launches run a
+ * separate instantiation of the kernel: the product kernel carries no stamps. */
+int mmqg_persist_set_trace(uint64_t* buf, int64_t words);
 int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_stream stream);
 
 /* mmqg_decoder_seq: AttnDecoder.forward (decoder.py:74-107) for T teacher-forced steps

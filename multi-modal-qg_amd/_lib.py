@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmqg_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LAYERS = 8
 
 K_MAJOR, MN_MAJOR = 0, 1
@@ -45,7 +45,8 @@ class LstmSeq(C.Structure):
                 ("dropout_p", c_fl), ("training", C.c_int32), ("seed", c_u64), ("stream_base", c_u64),
                 ("seed_offset", c_f),
                 ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f),
-                ("y", c_f), ("y_stride_t", c_i64), ("y_stride_b", c_i64)]
+                ("y", c_f), ("y_stride_t", c_i64), ("y_stride_b", c_i64),
+                ("persist_ws", c_f), ("persist_ws_bytes", c_i64)]
 
 
 class LstmSeqGrad(C.Structure):
@@ -161,6 +162,9 @@ SIGNATURES = {
     "mmqg_transpose_f32": [c_f, c_i, c_i, c_i, c_f, c_i, c_f],
     "mmqg_transpose_f32_batch": [C.POINTER(TransposeJob), c_i, c_f],
     "mmqg_lstm_seq_fwd": [C.POINTER(LstmSeq), c_f],
+    "mmqg_lstm_seq_persist_ws_bytes": [C.c_int, C.c_int, C.c_int, C.c_int],
+    "mmqg_persist_launch_count": [],
+    "mmqg_persist_set_trace": [c_f, c_i64],
     "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
     "mmqg_decoder_decode_run": [C.POINTER(DecoderDecode), c_f],
     "mmqg_sample_gumbel": [c_f, c_i, c_i, c_i, c_u64, c_u64, c_f, c_f],
@@ -190,7 +194,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "mmqg_last_error" else C.c_int
+        fn.restype = C.c_char_p if name == "mmqg_last_error" else (C.c_int64 if name.endswith("_ws_bytes") else C.c_int)
     got = lib.mmqg_abi_version()
     if got != ABI_VERSION:
         raise BackendError(f"mmqg: ABI mismatch: library {got}, binding {ABI_VERSION}")

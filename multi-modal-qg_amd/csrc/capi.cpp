@@ -20,6 +20,9 @@ const char* get_error() { return g_err; }
 
 int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s);
 int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s);
+int64_t lstm_persist_ws_bytes(int T, int B, int L, int H);
+int persist_launch_count();
+void persist_set_trace(unsigned long long* buf, int64_t words);
 int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s);
 int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, hipStream_t s);
 int decoder_decode(const mmqg_decoder_decode& d, hipStream_t s);
@@ -127,6 +130,9 @@ int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream) {
     MMQG_REQUIRE(d, "mmqg_lstm_seq_fwd: null descriptor");
     return lstm_seq_fwd(*d, S(stream));
 }
+int64_t mmqg_lstm_seq_persist_ws_bytes(int T, int B, int L, int H) { return lstm_persist_ws_bytes(T, B, L, H); }
+int mmqg_persist_launch_count(void) { return persist_launch_count(); }
+int mmqg_persist_set_trace(uint64_t* buf, int64_t words) { persist_set_trace(reinterpret_cast<unsigned long long*>(buf), words); return 0; }
 int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_stream stream) {
     MMQG_REQUIRE(d && g, "mmqg_lstm_seq_bwd: null descriptor");
     return lstm_seq_bwd(*d, *g, S(stream));

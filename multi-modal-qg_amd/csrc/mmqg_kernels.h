@@ -114,6 +114,13 @@ int axpy(float* y, const float* x, float alpha, int64_t n, hipStream_t s);
 int add_rows_strided(float* dst, int64_t dst_stride, const float* src, int64_t src_stride, int rows, int cols,
                      hipStream_t s);
 
+// ---- persist.hip: the forward time loop of an LSTM stack as one persistent launch ------
+bool lstm_persist_shape_ok(int T, int B, int L, int H);
+int64_t lstm_persist_ws_bytes(int T, int B, int L, int H);
+// 0 = done, 1 = not eligible (caller falls back to one launch per diagonal), < 0 = error
+int lstm_seq_fwd_persistent(const mmqg_lstm_seq& d, hipStream_t s);
+int persist_launch_count();
+
 // ---- cnn.hip --------------------------------------------------------------------------
 int frame_cnn_fwd(const mmqg_frame_cnn& d, hipStream_t s);
 int frame_cnn_bwd(const mmqg_frame_cnn& d, const mmqg_frame_cnn_grad& g, hipStream_t s);

@@ -125,6 +125,10 @@ static bool lstm_wavefront_fwd_ok(const mmqg_lstm_seq& d) {
 int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s) {
     MMQG_TRY(check_lstm(d, "lstm_seq_fwd"));
     if (d.B == 0) return 0;
+    if (d.persist_ws && !g_no_fuse()) {      // the whole time loop as one persistent launch (persist.hip)
+        const int rc = lstm_seq_fwd_persistent(d, s);
+        if (rc <= 0) return rc;
+    }
     if (lstm_wavefront_fwd_ok(d)) return lstm_seq_fwd_wavefront(d, s);
     const int T = d.T, B = d.B, H = d.H, L = d.L;
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;

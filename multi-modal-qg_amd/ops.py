@@ -268,16 +268,19 @@ class LSTMSeqFn(torch.autograd.Function):
         hdrop = torch.empty(L - 1, T, B, H, device=dev, dtype=torch.float32) if drop else None
         d.gates, d.hs, d.cs, d.hdrop = gates.data_ptr(), hs.data_ptr(), cs.data_ptr(), ptr(hdrop)
         d.y = None
+        nws = int(_lib.load().mmqg_lstm_seq_persist_ws_bytes(T, B, L, H))     # > 0: the persistent time loop takes this shape
+        pws = torch.zeros((nws + 3) // 4, device=dev, dtype=torch.float32) if nws > 0 else None
+        d.persist_ws, d.persist_ws_bytes = ptr(pws), nws
         check(_lib.load().mmqg_lstm_seq_fwd(C.byref(d), _stream()), "lstm_seq_fwd")
         ctx.desc = d
-        ctx.keep = (x, h0, c0, params, gates, hs, cs, hdrop)
+        ctx.keep = (x, h0, c0, params, gates, hs, cs, hdrop, pws)
         y = hs[L - 1, 1:].clone()
         return y, hs[:, T].clone(), cs[:, T].clone()
 
     @staticmethod
     def backward(ctx, dy, dhT, dcT):
         d = ctx.desc
-        x, h0, c0, params, gates, hs, cs, hdrop = ctx.keep
+        x, h0, c0, params, gates, hs, cs, hdrop, _ = ctx.keep
         T, B, L, H, In = d.T, d.B, d.L, d.H, d.In
         dev = x.device
         g = _lib.LstmSeqGrad()

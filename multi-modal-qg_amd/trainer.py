@@ -228,6 +228,8 @@ class BatchedTrainer:
         gv.dgates, gv.dh, gv.dc = w["dgates_v"].data_ptr(), w["dh_v"].data_ptr(), w["dc_v"].data_ptr()
         gv.dx, gv.lddx = w["dfeats"].data_ptr(), self.Fin
         dv.w_hhT[0] = w["whhT_v"].data_ptr()
+        # (no persistent time loop for the frame LSTM: it runs on the side stream BESIDE the text encoder's, and two
+        # persistent launches that cannot share a CU may each end up half resident and wait for the other forever)
         self.d_vid, self.g_vid = dv, gv
         # text encoder -> text rows of the value tensor
         dt, gt = _lib.LstmSeq(), _lib.LstmSeqGrad()
@@ -247,6 +249,7 @@ class BatchedTrainer:
             dt.w_hhT[l] = w["whhT_t"][l].data_ptr()
             if l > 0:
                 dt.w_ihT[l] = w["wihT_t"][l].data_ptr()
+        self._persist_ws(dt, "pws_t")
         self.d_text, self.g_text = dt, gt
         # decoder
         dd, gd = _lib.DecoderSeq(), _lib.DecoderSeqGrad()
@@ -286,6 +289,14 @@ class BatchedTrainer:
                 dd.w_ihT[l] = w["wihT_d"][l].data_ptr()
         dd.w_ih0cT, dd.w_attn_hT = w["wih0cT"].data_ptr(), w["wattn_hT"].data_ptr()
         self.d_dec, self.g_dec = dd, gd
+
+    def _persist_ws(self, d, key):
+        """Workspace of the persistent forward time loop (exchange buffers + barrier words), when the
+        library takes this shape (csrc/persist.hip)."""
+        n = int(_lib.load().mmqg_lstm_seq_persist_ws_bytes(d.T, d.B, d.L, d.H))
+        if n > 0:
+            self.ws[key] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)
+            d.persist_ws, d.persist_ws_bytes = self.ws[key].data_ptr(), n
 
     def set_seed(self, seed: int) -> None:
         """Seed of the dropout streams (mixed with the device-side step counter at run time)."""

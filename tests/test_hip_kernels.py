@@ -362,12 +362,17 @@ def test_adam_matches_oracle_over_steps(mm):
 
 
 # ------------------------------------------------------------------------ sequence executors
-@pytest.mark.parametrize("T,B,L,H,In,p", [(5, 3, 3, 16, 12, 0.0), (4, 6, 2, 32, 20, 0.3), (7, 4, 1, 24, 40, 0.0)])
+@pytest.mark.parametrize("T,B,L,H,In,p", [(5, 3, 3, 16, 12, 0.0), (4, 6, 2, 32, 20, 0.3), (7, 4, 1, 24, 40, 0.0),
+                                          # shapes the persistent forward time loop takes (csrc/persist.hip): partial
+                                          # row blocks, 1..4 row blocks per unit, 1..3 layers, dropout on and off
+                                          (6, 5, 3, 128, 40, 0.25), (5, 20, 2, 128, 64, 0.0), (4, 64, 1, 256, 32, 0.0),
+                                          (9, 33, 3, 192, 24, 0.3), (3, 48, 2, 512, 16, 0.2)])
 def test_lstm_sequence_executor_forward_backward(mm, T, B, L, H, In, p):
     """mmqg_lstm_seq_fwd/bwd (autograd wrapper LSTMSeqFn) vs the oracle's stacked cell loop, with
     a given initial state and the executor's own dropout masks replayed into the oracle."""
     _lib, ops = mm
     from oracle import mmqg_oracle as O
+    persistent_before = _lib.load().mmqg_persist_launch_count()
     g = torch.Generator().manual_seed(T * B + H)
     params = {}
     for l in range(L):
@@ -385,6 +390,8 @@ def test_lstm_sequence_executor_forward_backward(mm, T, B, L, H, In, p):
             for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
     xd, h0d, c0d = (dev(t).requires_grad_(True) for t in (x, h0, c0))
     y, hT, cT = ops.lstm_seq(xd, h0d, c0d, flat, p, True, seed)
+    took_persistent = _lib.load().mmqg_persist_launch_count() - persistent_before
+    assert took_persistent == (1 if H >= 128 else 0), "the persistent time loop must take exactly the wide shapes"
     ((y * dev(gy)).sum() + (hT * dev(ghT)).sum() + (cT * dev(gcT)).sum()).backward()
     # replay the executor's masks: stream id = stream_base + l*T + t, element = b*H + j
     base = (next(ops._stream_counter) - 1) << 32

@@ -38,7 +38,8 @@ def test_ctypes_structs_match_the_c_layout(lib_mod, tmp_path):
     """Compile a tiny C program against include/mmqg.h that prints sizeof/offsetof and compare
     with the ctypes mirror."""
     fields = {"mmqg_attn_values": ("AttnValues", ["B", "text", "video_stride_b", "mask_mode"]),
-              "mmqg_lstm_seq": ("LstmSeq", ["x", "w_hh", "w_hhT", "w_ihT", "lens", "seed", "seed_offset", "gates", "y_stride_b"]),
+              "mmqg_lstm_seq": ("LstmSeq", ["x", "w_hh", "w_hhT", "w_ihT", "lens", "seed", "seed_offset", "gates", "y_stride_b",
+                                            "persist_ws", "persist_ws_bytes"]),
               "mmqg_lstm_seq_grad": ("LstmSeqGrad", ["dy", "dgates", "lddx", "db_hh", "dc0", "phase"]),
               "mmqg_decoder_seq": ("DecoderSeq", ["values", "xemb", "b_hh", "w_ihT", "w_attn_hT", "seed_offset", "scores",
                                                   "ld_attn", "hdrop", "phase", "h0_stride_l"]),

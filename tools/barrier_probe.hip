@@ -147,11 +147,24 @@ __global__ __launch_bounds__(512) void exchange_loop(XBar* b, int iters, u32* ac
         else ok = SC1 ? bar_flat<false>(b, gridDim.x, 2 + i) : bar_flat<true>(b, gridDim.x, 2 + i);
         if (!ok) return;
         if (read_all) {
-            for (int k = threadIdx.x * 4; k < n_words; k += blockDim.x * 4) {
-                u32x4 v;
-                if (SC1) v = __builtin_amdgcn_raw_buffer_load_b128(rs, k * 4, 0, 16);
-                else v = *reinterpret_cast<const u32x4*>(dst + k);
-                bad += (v.x != expect(i, k)) + (v.y != expect(i, k + 1)) + (v.z != expect(i, k + 2)) + (v.w != expect(i, k + 3));
+            // 8 independent 16-byte loads in flight per lane (a latency-bound read loop would hide the real rate)
+            const int stride = blockDim.x * 4;
+            for (int k0 = threadIdx.x * 4; k0 < n_words; k0 += 8 * stride) {
+                u32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * stride;
+                    if (k < n_words) {
+                        if (SC1) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, k * 4, 0, 16);
+                        else v[u] = *reinterpret_cast<const u32x4*>(dst + k);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u * stride;
+                    if (k < n_words)
+                        bad += (v[u].x != expect(i, k)) + (v[u].y != expect(i, k + 1)) + (v[u].z != expect(i, k + 2)) + (v[u].w != expect(i, k + 3));
+                }
             }
         }
     }
