@@ -61,7 +61,7 @@ def load_training_state(path, trainer) -> dict:
         raise ValueError("checkpoint was written for a different parameter layout")
     for name in ("flat_p", "flat_m", "flat_v", "emb_m2", "emb_v2"):
         getattr(trainer, name).copy_(st[name])
-    trainer.step_dev.fill_(st["step"])
+    trainer.counters.fill_(st["step"])       # completed steps = Adam's step number
     trainer.set_seed(st["seed"])
     trainer.video.load_state_dict(st["bn_buffers"], strict=False)
     return st

@@ -50,7 +50,7 @@ class GradReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = exchange_needed(group)
-        self._pending: List = []
+        self._pending: Dict[str, object] = {}
 
     def reduce(self, name: str) -> None:
         if not self.active or name not in self.buckets or name in self._done:
@@ -58,7 +58,14 @@ class GradReducer:
         self._done.add(name)
         a, b = self.buckets[name]
         if b > a:
-            self._pending.append(dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._pending[name] = dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self, *names: str) -> None:
+        """Make the current stream wait for these buckets' all-reduces (the others stay in flight)."""
+        for name in names:
+            w = self._pending.pop(name, None)
+            if w is not None:
+                w.wait()
 
     def reduce_remaining(self) -> None:
         for name in self.buckets:
@@ -70,7 +77,7 @@ class GradReducer:
         self.finish()
 
     def finish(self) -> None:
-        for w in self._pending:
+        for w in self._pending.values():
             w.wait()
         self._pending.clear()
         self._done.clear()

@@ -145,7 +145,11 @@ class BatchedTrainer:
         e0, e1 = self.segments["emb"]
         self.emb_m2 = torch.zeros(e1 - e0, device=self.dev, dtype=torch.float32)   # second optimizer's moments
         self.emb_v2 = torch.zeros(e1 - e0, device=self.dev, dtype=torch.float32)
-        self.step_dev = torch.zeros(1, device=self.dev, dtype=torch.int32)
+        # two device counters: step_dev = completed steps (mixed into the dropout seed while a step runs, so it may
+        # only advance when the step's backward is over); adam_dev = Adam's 1-based step number, advanced before the
+        # FIRST optimizer launch of a step (a data-parallel step starts its Adam early, beside the text encoder's backward)
+        self.counters = torch.zeros(2, device=self.dev, dtype=torch.int32)
+        self.step_dev, self.adam_dev = self.counters[0:1], self.counters[1:2]
         self.n_params = total
 
     # ------------------------------------------------------------------------ workspaces
@@ -505,25 +509,29 @@ class BatchedTrainer:
         out = self.dec.out_layer
         htop = w["hs_d"][L - 1, 1:].reshape(R, H)
         demb = self.dec.emb_layer.weight.grad
-        if part != "b":
+        if part in ("all", "a", "dec"):
             self._backward_decoder(lib, w, s, logits, out, htop, R)
+        if part == "dec":
+            return
 
-        def enc_side():              # decoder weight gradients, frame encoder backward
+        def enc_side(which: str = "both"):   # decoder weight gradients ("s1"), frame encoder backward ("s2")
             s2 = ops._stream()
-            self.g_dec.phase = 2
-            check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s2), "decoder_seq_bwd(wgrad)")
-            self.g_dec.phase = 0
-            ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
-            if self.distributed and not torch.cuda.is_current_stream_capturing():
-                # the decoder bucket (everything but the embedding) is final here: start its all-reduce
-                # from the side stream so it runs beside the text encoder's backward
-                self.reducer.reduce("dec")
-            self.g_vid.phase = 0
-            check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s2), "lstm_seq_bwd(frames)")
-            if self._cnn_on:
-                check(lib.mmqg_frame_cnn_bwd(C.byref(self.d_cnn), C.byref(self.g_cnn), s2), "frame_cnn_bwd")
-            if self.distributed and not torch.cuda.is_current_stream_capturing():
-                self.reducer.reduce("vid")          # frame encoder gradients are final too
+            if which in ("both", "s1"):
+                self.g_dec.phase = 2
+                check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s2), "decoder_seq_bwd(wgrad)")
+                self.g_dec.phase = 0
+                ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
+                if self.distributed and not torch.cuda.is_current_stream_capturing():
+                    # the decoder bucket (everything but the embedding) is final here: start its all-reduce
+                    # from the side stream so it runs beside the text encoder's backward
+                    self.reducer.reduce("dec")
+            if which in ("both", "s2"):
+                self.g_vid.phase = 0
+                check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s2), "lstm_seq_bwd(frames)")
+                if self._cnn_on:
+                    check(lib.mmqg_frame_cnn_bwd(C.byref(self.d_cnn), C.byref(self.g_cnn), s2), "frame_cnn_bwd")
+                if self.distributed and not torch.cuda.is_current_stream_capturing():
+                    self.reducer.reduce("vid")          # frame encoder gradients are final too
 
         def enc_chain():             # text encoder backward: the rest of the dependent chain
             self.g_text.phase = 1
@@ -535,6 +543,8 @@ class BatchedTrainer:
 
         if part == "a":
             enc_side()
+        elif part in ("s1", "s2"):
+            enc_side(part)
         elif part == "b":
             enc_chain()
         elif self.chain_first:
@@ -548,7 +558,7 @@ class BatchedTrainer:
                 enc_side()
             enc_chain()
             self._join()
-        if self.grad_hook and part != "a":
+        if self.grad_hook and part in ("all", "b"):
             self.grad_hook(self, "all")
 
     def _backward_decoder(self, lib, w, s, logits, out, htop, R):
@@ -603,18 +613,27 @@ class BatchedTrainer:
             self._tr_jobs = arr
         check(_lib.load().mmqg_transpose_f32_batch(self._tr_jobs, len(self._tr_jobs), ops._stream()), "transpose_f32_batch")
 
-    def _adam(self):
+    def _adam(self, part: str = "all"):
+        """Adam over the flat buffer.  part 'all': everything (+ the embedding's second optimizer), both counters
+        advance.  Data-parallel graph step: 'early' = decoder + frame-encoder segments as soon as their buckets are
+        reduced (advances adam_dev only: the running backward still reads step_dev), 'late' = the rest."""
         lib, s = _lib.load(), ops._stream()
         b1, b2 = self.betas
         scale = 1.0 / self.world
-        check(lib.mmqg_counter_add(self.step_dev.data_ptr(), 1, s), "counter_add")
-        check(lib.mmqg_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                                 self.flat_v.data_ptr(), self.n_params, self.lr, b1, b2, self.eps,
-                                 self.step_dev.data_ptr(), scale, s), "adam_step")
-        e0, e1 = self.segments["emb"]
-        check(lib.mmqg_adam_step(self.flat_p.data_ptr() + 4 * e0, self.flat_g.data_ptr() + 4 * e0,
-                                 self.emb_m2.data_ptr(), self.emb_v2.data_ptr(), e1 - e0, self.lr, b1, b2, self.eps,
-                                 self.step_dev.data_ptr(), scale, s), "adam_step(embedding, 2nd optimizer)")
+        split = self.reducer.buckets["rest"][0] if "rest" in self.reducer.buckets and "vid" in self.reducer.buckets else 0
+        if part in ("all", "early"):
+            check(lib.mmqg_counter_add(self.adam_dev.data_ptr(), 1, s), "counter_add")
+        lo, hi = {"all": (0, self.n_params), "early": (0, split), "late": (split, self.n_params)}[part]
+        if hi > lo:
+            check(lib.mmqg_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
+                                     self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, self.lr, b1,
+                                     b2, self.eps, self.adam_dev.data_ptr(), scale, s), "adam_step")
+        if part in ("all", "late"):
+            e0, e1 = self.segments["emb"]
+            check(lib.mmqg_adam_step(self.flat_p.data_ptr() + 4 * e0, self.flat_g.data_ptr() + 4 * e0,
+                                     self.emb_m2.data_ptr(), self.emb_v2.data_ptr(), e1 - e0, self.lr, b1, b2, self.eps,
+                                     self.adam_dev.data_ptr(), scale, s), "adam_step(embedding, 2nd optimizer)")
+            check(lib.mmqg_counter_add(self.step_dev.data_ptr(), 1, s), "counter_add")
 
     def _allreduce(self):
         if self.distributed:
@@ -647,7 +666,7 @@ class BatchedTrainer:
 
     # ------------------------------------------------------------------------ hipGraph
     def _graph_body(self, part: str = "all"):
-        if part != "b":
+        if part in ("all", "dec"):
             self.flat_g.zero_()
             self._forward(True)
         self._loss_and_backward(part)
@@ -656,11 +675,15 @@ class BatchedTrainer:
         self.load_batch(batch)
         if self._graph is not None and self._graph_cnn != self._cnn_on:
             self._graph = None                                  # raw frames <-> features: different launch sequence
-        # single GPU: [zero, forward, loss, backward] | [Adam].  Data parallel: [zero, forward, loss, decoder
-        # backward, decoder weight gradients, frame encoder backward] | all-reduce(dec), all-reduce(vid) start |
-        # [text encoder backward] | all-reduce(rest), wait | [Adam]: RCCL stays outside every capture and the
-        # first two buckets travel while the text encoder's backward runs.
-        parts = ("a", "b") if self.distributed else ("all",)
+        # single GPU: [zero, forward, loss, backward with its two branches] | [Adam].
+        # Data parallel: RCCL stays outside every capture, so the step is cut where gradient buckets become final
+        # and the two branches of the encoder backward are replayed on two streams:
+        #   main : [zero, forward, loss, decoder backward] ............ [text encoder backward] join, all-reduce(rest),
+        #                                                                                       wait, [Adam(rest)]
+        #   side :    [decoder weight grads] all-reduce(dec) [frame encoder backward] all-reduce(vid) wait [Adam(dec, vid)]
+        # i.e. the first two buckets travel, and their Adam runs, beside the text encoder's backward.
+        dp = self.distributed
+        parts = ("dec", "s1", "s2", "b") if dp else ("all",)
         if self._graph is None:
             self._graph_cnn = self._cnn_on
             warm = torch.cuda.Stream()
@@ -675,28 +698,44 @@ class BatchedTrainer:
             for b, v in zip(bn_stats, saved):  # the warm-up pass must not count as a training step
                 b.copy_(v)
             torch.cuda.synchronize()
-            if self.distributed:
+            if dp:
                 self.reducer.discard()          # the warm-up pass ran eagerly and may have queued reductions
-            self._graphs = []
+            self._graphs = {}
             pool = None
             for part in parts:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     self._graph_body(part)
                 pool = g.pool()
-                self._graphs.append(g)
-            self._graph = self._graphs[0]
-            self._graph_adam = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_adam, pool=pool, capture_error_mode="thread_local"):
-                self._adam()
-        self._graphs[0].replay()
+                self._graphs[part] = g
+            self._graph = self._graphs[parts[0]]
+            for part in (("early", "late") if dp else ("all",)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    self._adam(part)
+                self._graphs["adam_" + part] = g
+        G = self._graphs
+        if not dp:
+            G["all"].replay()
+            self._count_bn_batches()
+            G["adam_all"].replay()
+            return self.ws["loss"]
+        main = torch.cuda.current_stream()
+        G["dec"].replay()
         self._count_bn_batches()
-        if self.distributed:
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            G["s1"].replay()
             self.reducer.reduce("dec")
+            G["s2"].replay()
             self.reducer.reduce("vid")
-            self._graphs[1].replay()
-        self._allreduce()
-        self._graph_adam.replay()
+            self.reducer.wait("dec", "vid")
+            G["adam_early"].replay()
+        G["b"].replay()
+        main.wait_stream(self._side)            # the embedding gradient has a part from either branch
+        self.reducer.reduce_remaining()
+        self.reducer.finish()
+        G["adam_late"].replay()
         return self.ws["loss"]
 
     # ------------------------------------------------------------------------- inference
