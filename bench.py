@@ -57,6 +57,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
     ap.add_argument("--kernel-iters", type=int, default=200, help="launches per kernel-duration measurement")
+    ap.add_argument("--skip-zero-rows", action="store_true",
+                    help="attention kernels skip the zero-padded value rows (identical results; NOT the default: the "
+                         "roofline is defined on streaming the padded extents)")
     return ap.parse_args(argv)
 
 
@@ -146,9 +149,15 @@ def kernel_rooflines(tr, w, iters):
     B, Td, ldS, Cw = tr.B, tr.Td, tr.ldS, tr.Cw
     sc, at, cx = ws["scores"], ws["attn"], ws["ctx"]
 
+    # the roofline is defined on the kernel that streams every value row (the padded extents the reference's bmm
+    # reads): always measured with zero_past_len = 0, whatever the step itself was run with
+    vstream = type(d.values)()
+    C.memmove(C.addressof(vstream), C.addressof(d.values), C.sizeof(vstream))
+    vstream.zero_past_len = 0
+
     def attn(i):
         t = i % Td
-        _lib.check(lib.mmqg_attn_softmax_context_fwd(C.byref(d.values), sc[t].data_ptr(), ldS, at[t].data_ptr(), ldS,
+        _lib.check(lib.mmqg_attn_softmax_context_fwd(C.byref(vstream), sc[t].data_ptr(), ldS, at[t].data_ptr(), ldS,
                                                      cx[t].data_ptr(), Cw, s))
     dt = time_launches(attn, iters)
     nbytes, _ = attention_bytes(w, B)
@@ -163,7 +172,7 @@ def kernel_rooflines(tr, w, iters):
     descs = []
     for r in range(n_rot):
         v = type(d.values)()
-        C.memmove(C.addressof(v), C.addressof(d.values), C.sizeof(v))
+        C.memmove(C.addressof(v), C.addressof(vstream), C.sizeof(v))
         base = rot[r].data_ptr()
         v.text, v.audio, v.video = base, base + 4 * tr.off_audio, base + 4 * tr.off_video
         descs.append(v)
@@ -290,7 +299,7 @@ def main(argv=None):
     B = a.batch or w.batch
     vid, text, dec = build_models(w, dev, seed=0)          # same seed on every rank: identical replicas
     tr = BatchedTrainer(vid, text, dec, batch_size=B, n_frames=w.n_frames, ctx_len=w.ctx_len, tgt_len=w.tgt_len,
-                        lr=1e-4, seed=1234, use_graph=not a.no_graph).train()
+                        lr=1e-4, seed=1234, use_graph=not a.no_graph, skip_zero_value_rows=a.skip_zero_rows).train()
     batches = [synthetic_batch(w, seed=rank * 1000 + i, batch=B) for i in range(4)]    # each rank its own shard
     batches = [{k: v.to(dev) for k, v in b.items()} for b in batches]
 
@@ -324,6 +333,7 @@ def main(argv=None):
                       "vocab": w.vocab, "emb_dim": w.emb_dim, "hidden": w.hidden, "layers": w.layers,
                       "attn_widths": [w.text_max_length, w.av_max_length], "dropout": w.dropout,
                       "parallelism": f"dp{world}", "hipgraph": bool(tr.use_graph),
+                      "skip_zero_value_rows": bool(a.skip_zero_rows),
                       "world_size": torch.distributed.get_world_size() if use_pg else 1,
                       "collective_backend": backend},
            "final_loss": round(loss_val, 4)}

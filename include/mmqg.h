@@ -88,6 +88,11 @@ typedef struct {
     const int32_t* text_len;
     const int32_t* av_len;
     int32_t mask_mode;
+    int32_t zero_past_len;    /* 1: the caller guarantees that value rows at and past text_len[b] / av_len[b] are all
+                                 zero (train.py:156-160 pads the encoder outputs with zeros) — the kernels then skip
+                                 those rows instead of streaming them; results are identical (a zero row contributes
+                                 nothing to a context and has a zero weight gradient).  0 (default): every row is read,
+                                 as the reference's bmm does.  Needs text_len and av_len. */
 } mmqg_attn_values;
 
 /* scores [B][ld_s] (pre-softmax, Lt+2*Lav wide) -> attn [B][ld_a] (must NOT alias scores) and

@@ -30,7 +30,8 @@ class AttnValues(C.Structure):
                 ("text", c_f), ("text_stride_b", c_i64),
                 ("audio", c_f), ("audio_stride_b", c_i64),
                 ("video", c_f), ("video_stride_b", c_i64),
-                ("text_len", c_f), ("av_len", c_f), ("mask_mode", C.c_int32)]
+                ("text_len", c_f), ("av_len", c_f), ("mask_mode", C.c_int32),
+                ("zero_past_len", C.c_int32)]
 
 
 _PTRS = c_f * MAX_LAYERS

@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
     // 283 / 101 rows).
     constexpr int kU = 4;
     float4 cur[kU], nxt[kU];
-    const int last_row = sg.L - 1, row_len = sg.D;
+    // rows to stream: all of them, or only the rows before the valid length when the caller vouches that the
+    // rest is zero padding (zero_past_len); the softmax below always spans all L scores
+    const int n_stream = a.v.zero_past_len ? max(1, min(sg.L, sg.valid)) : sg.L;
+    const int last_row = n_stream - 1, row_len = sg.D;
     auto fetch = [V, last_row, row_len](float4 (&dst)[kU], int first) {     // (captures by value: no struct reference)
 #pragma unroll
         for (int u = 0; u < kU; ++u)
@@ -171,12 +174,12 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
     if (col_ok) {
         if (vec) {
-            for (int base = rg; base < sg.L; base += kU * kGroups) {
+            for (int base = rg; base < n_stream; base += kU * kGroups) {
                 float wv[kU];
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
                     const int i = base + u * kGroups;
-                    wv[u] = i < sg.L ? w[i] : 0.f;
+                    wv[u] = i < n_stream ? w[i] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < kU; u += 2) {
@@ -186,10 +189,10 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
                 }
 #pragma unroll
                 for (int u = 0; u < kU; ++u) cur[u] = nxt[u];
-                if (base + 2 * kU * kGroups < sg.L) fetch(nxt, base + 2 * kU * kGroups);
+                if (base + 2 * kU * kGroups < n_stream) fetch(nxt, base + 2 * kU * kGroups);
             }
         } else {
-            for (int i = rg; i < sg.L; i += kGroups) {
+            for (int i = rg; i < n_stream; i += kGroups) {
                 const float* r = V + (int64_t)i * sg.D;
                 const float w0 = w[i];
                 acc0.x += w0 * r[0];
@@ -233,9 +236,14 @@ __global__ __launch_bounds__(256) void attn_dweights_kernel(AttnBwdK a) {
     const float* g = a.dctx + (int64_t)b * a.ld_c + sg.ctx_off;
     float* out = a.dscores + (int64_t)b * a.ld_ds + sg.seg_off;
     const int row_end = min(sg.L, (blk + 1) * kRowBlock);
+    const int n_stream = a.v.zero_past_len ? min(sg.L, sg.valid) : sg.L;      // rows past it are zero padding
     for (int i = blk * kRowBlock + wave; i < row_end; i += 4) {
         const float* r = sg.base + (int64_t)i * sg.D;
         float acc = 0.f;
+        if (i >= n_stream) {
+            if (lane == 0) out[i] = 0.f;
+            continue;
+        }
         if (vec) {
             for (int c = 4 * lane; c < sg.D; c += 256) {
                 const float4 x = *reinterpret_cast<const float4*>(r + c);
@@ -336,6 +344,7 @@ int check_values(const mmqg_attn_values& v, const char* who) {
     MMQG_REQUIRE(v.mask_mode == MMQG_MASK_REFERENCE_NOOP || v.mask_mode == MMQG_MASK_INTENDED, "%s: bad mask_mode", who);
     MMQG_REQUIRE(v.mask_mode == MMQG_MASK_REFERENCE_NOOP || (v.text_len && v.av_len),
                  "%s: MMQG_MASK_INTENDED needs text_len and av_len", who);
+    MMQG_REQUIRE(!v.zero_past_len || (v.text_len && v.av_len), "%s: zero_past_len needs text_len and av_len", who);
     return 0;
 }
 

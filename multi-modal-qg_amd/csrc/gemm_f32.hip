@@ -428,6 +428,10 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
         }
     }
     if (small) return launch<64, 64, 32>(a, a_layout, b_layout, s);
+    static const int tile_env = env_int("MMQG_GEMM_TILE", 0);      // experiments: 1 = 64x128x32, 2 = 128x64x32, 3 = 64x128x16
+    if (tile_env == 1) return launch<64, 128, 32>(a, a_layout, b_layout, s);
+    if (tile_env == 2) return launch<128, 64, 32>(a, a_layout, b_layout, s);
+    if (tile_env == 3) return launch<64, 128, 16>(a, a_layout, b_layout, s);
     if (big_bk == 32) return launch<128, 128, 32>(a, a_layout, b_layout, s);
     return launch<128, 128, 16>(a, a_layout, b_layout, s);
 }

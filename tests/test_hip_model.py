@@ -411,6 +411,24 @@ def _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode, tol=TOL, wto
                 close(p, osd[k], tol=wtol, what=f"weight {k} after Adam")
 
 
+def test_skipping_zero_padded_value_rows_changes_nothing(mm):
+    """skip_zero_value_rows: the attention kernels stop at each question's context length / frame count instead of
+    streaming the zero padding up to 283 / 101 rows — loss and every gradient must come out the same."""
+    from mmqg_amd.synthetic import WORKLOADS, build_models, synthetic_batch
+    w = WORKLOADS["config2"]
+    batch = synthetic_batch(w, seed=19, batch=3, ragged=True)
+    out = []
+    for skip in (False, True):
+        vid, text, dec = build_models(w, "cuda", seed=4)
+        tr = _trainer(mm, vid, text, dec, batch, seed=9, skip_zero_value_rows=skip).train()
+        loss = float(tr.forward_backward(batch))
+        out.append((loss, tr.flat_g.clone(), tr.ws["attn"].clone(), tr.ws["ctx"].clone()))
+    assert out[0][0] == out[1][0]
+    for a, b, what in zip(out[0][1:], out[1][1:], ("gradients", "attention weights", "contexts")):
+        close(b, a, tol=1e-6, what=f"{what} with zero rows skipped")
+    assert float(out[0][1].abs().max()) > 0
+
+
 def test_graph_replay_equals_eager_steps(mm):
     from mmqg_amd.synthetic import build_models
     w, batch = _oracle_setup(4, 9, 0.2, True)

@@ -37,7 +37,7 @@ def test_library_exports_every_symbol_declared_in_the_header(lib_mod):
 def test_ctypes_structs_match_the_c_layout(lib_mod, tmp_path):
     """Compile a tiny C program against include/mmqg.h that prints sizeof/offsetof and compare
     with the ctypes mirror."""
-    fields = {"mmqg_attn_values": ("AttnValues", ["B", "text", "video_stride_b", "mask_mode"]),
+    fields = {"mmqg_attn_values": ("AttnValues", ["B", "text", "video_stride_b", "mask_mode", "zero_past_len"]),
               "mmqg_lstm_seq": ("LstmSeq", ["x", "w_hh", "w_hhT", "w_ihT", "lens", "seed", "seed_offset", "gates", "y_stride_b",
                                             "persist_ws", "persist_ws_bytes"]),
               "mmqg_lstm_seq_grad": ("LstmSeqGrad", ["dy", "dgates", "lddx", "db_hh", "dc0", "phase"]),

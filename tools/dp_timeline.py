@@ -19,6 +19,6 @@ busy_end = t0
 for r in step:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = (s - busy_end) / 1e3
-    if (e - s) > 30000 or gap > 5 or "nccl" in r["Kernel_Name"].lower() or "rccl" in r["Kernel_Name"].lower():
+    if (e - s) > 25000 or gap > 3 or "nccl" in r["Kernel_Name"].lower() or "rccl" in r["Kernel_Name"].lower():
         print(f"t={(s - t0) / 1e3:8.1f}  q{r['Queue_Id']:>2s}  dur {(e - s) / 1e3:8.1f}  idle-before {gap:6.1f}  {nm(r)}")
     busy_end = max(busy_end, e)
