@@ -99,6 +99,8 @@ class BatchedTrainer:
         self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
         self._tr_jobs = None
         self._audio_rows = 0
+        # (stream priorities were tried both ways — side low, chain high — and change nothing: the range on this
+        # stack is only (0, -1) and workgroup arbitration between queues does not follow it)
         self._side = torch.cuda.Stream(device=self.dev)
         self.chain_first = os.environ.get("MMQG_SIDE_FIRST", "0") != "1"
         if os.environ.get("MMQG_NO_AHEAD", "0") != "1":      # look-ahead recurrent products in the decoder's backward loop
