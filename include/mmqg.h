@@ -104,6 +104,10 @@ int mmqg_attn_softmax_context_fwd(const mmqg_attn_values* v, const float* scores
 int mmqg_attn_context_bwd(const mmqg_attn_values* v, const float* attn, int ld_a,
                           const float* dctx, int ld_c, const float* dattn, int ld_da,
                           float* dscores, int ld_ds, mmqg_stream stream);
+/* the same for callers that kept the forward's contexts ctx [B][ld_x]: the softmax Jacobian's row dot
+ * sum_j attn_j d(attn)_j equals ctx . dctx per modality, so ONE kernel writes dscores (no dattn term) */
+int mmqg_attn_context_bwd_fused(const mmqg_attn_values* v, const float* attn, int ld_a, const float* ctx, int ld_x,
+                                const float* dctx, int ld_c, float* dscores, int ld_ds, mmqg_stream stream);
 /* gradient of the first n_rows value rows of one modality, summed over T steps:
  * out[b][row][:] (+)= sum_t attn[t][b][seg_off+row] * dctx[t][b][ctx_off : ctx_off+D] */
 int mmqg_attn_dvalues(int T, int B, int n_rows, int D,

@@ -150,6 +150,7 @@ SIGNATURES = {
     "mmqg_embedding_bwd": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f],
     "mmqg_attn_softmax_context_fwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f],
     "mmqg_attn_context_bwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f],
+    "mmqg_attn_context_bwd_fused": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f],
     "mmqg_attn_dvalues": [c_i, c_i, c_i, c_i, c_f, c_i64, c_i, c_i, c_f, c_i64, c_i, c_i, c_f, c_i64, c_i64, c_i, c_f],
     "mmqg_lstm_cell_fwd": [c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_i, c_fl, c_u64, c_u64, c_f],
     "mmqg_lstm_cell_bwd": [c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_i64, c_fl, c_u64, c_u64, c_f, c_i64, c_f, c_f, c_i,

@@ -220,16 +220,30 @@ struct AttnBwdK {
     mmqg_attn_values v;
     const float* dctx; int ld_c;
     float* dscores; int ld_ds;
-    int blocks_text, blocks_audio;
+    int blocks_text, blocks_audio, blocks_video;
     int vec_text, vec_audio, vec_video;
+    // fused softmax backward (both non-null): dscores = attn * (d(attn) - dot) with
+    // dot = sum_j attn_j d(attn)_j = (sum_j attn_j V_j) . dctx = ctx . dctx — the forward's context, no row pass
+    const float* attn; int ld_a;
+    const float* ctx; int ld_x;
 };
 
 // d(attn)[b][seg+i] = V[b][i][:] . dctx[b][ctx_off : ctx_off + D]
+// One workgroup per (question, modality, 32-row block), text blocks of the whole batch first (the heavy items,
+// as in the forward kernel).  A wave takes 4 rows at a time — lanes across the contiguous row — so 4 x D/256
+// independent 16-byte loads are in flight per lane before the first shuffle reduction (one row at a time exposed
+// a full memory latency per row).
 __global__ __launch_bounds__(256) void attn_dweights_kernel(AttnBwdK a) {
-    const int b = blockIdx.y;
-    int blk = blockIdx.x, modality = 0;
-    if (blk >= a.blocks_text) { blk -= a.blocks_text; modality = 1; }
-    if (modality == 1 && blk >= a.blocks_audio) { blk -= a.blocks_audio; modality = 2; }
+    int n = blockIdx.x, modality = 0, b, blk;
+    const int text_items = a.v.B * a.blocks_text;
+    if (n < text_items) {
+        b = n / a.blocks_text; blk = n - b * a.blocks_text;
+    } else {
+        n -= text_items;
+        const int per_q = a.blocks_audio + a.blocks_video;
+        b = n / per_q; blk = n - b * per_q; modality = 1;
+        if (blk >= a.blocks_audio) { blk -= a.blocks_audio; modality = 2; }
+    }
     const Segment sg = pick_segment(a.v, modality, b);
     const bool vec = modality == 0 ? a.vec_text : (modality == 1 ? a.vec_audio : a.vec_video);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -237,24 +251,49 @@ __global__ __launch_bounds__(256) void attn_dweights_kernel(AttnBwdK a) {
     float* out = a.dscores + (int64_t)b * a.ld_ds + sg.seg_off;
     const int row_end = min(sg.L, (blk + 1) * kRowBlock);
     const int n_stream = a.v.zero_past_len ? min(sg.L, sg.valid) : sg.L;      // rows past it are zero padding
-    for (int i = blk * kRowBlock + wave; i < row_end; i += 4) {
-        const float* r = sg.base + (int64_t)i * sg.D;
-        float acc = 0.f;
-        if (i >= n_stream) {
-            if (lane == 0) out[i] = 0.f;
-            continue;
-        }
-        if (vec) {
-            for (int c = 4 * lane; c < sg.D; c += 256) {
-                const float4 x = *reinterpret_cast<const float4*>(r + c);
-                const float4 y = *reinterpret_cast<const float4*>(g + c);
-                acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    constexpr int kR = 4;
+    const bool fused = a.attn != nullptr;
+    float dot = 0.f;
+    const float* arow = nullptr;
+    if (fused) {
+        const float* cx = a.ctx + (int64_t)b * a.ld_x + sg.ctx_off;
+        for (int c = lane; c < sg.D; c += 64) dot += cx[c] * g[c];
+        dot = wave_sum(dot);
+        arow = a.attn + (int64_t)b * a.ld_a + sg.seg_off;
+    }
+    for (int i0 = blk * kRowBlock + wave * kR; i0 < row_end; i0 += 4 * kR) {
+        float acc[kR];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) acc[r] = 0.f;
+        if (i0 < n_stream) {
+            const int last = n_stream - 1;
+            if (vec) {
+                for (int c = 4 * lane; c < sg.D; c += 256) {
+                    const float4 y = *reinterpret_cast<const float4*>(g + c);
+                    float4 x[kR];
+#pragma unroll
+                    for (int r = 0; r < kR; ++r)      // rows past the block / the stream: re-read a valid row, result unused
+                        x[r] = *reinterpret_cast<const float4*>(sg.base + (int64_t)min(i0 + r, last) * sg.D + c);
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) acc[r] += x[r].x * y.x + x[r].y * y.y + x[r].z * y.z + x[r].w * y.w;
+                }
+            } else {
+                for (int c = lane; c < sg.D; c += 64) {
+                    const float y = g[c];
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) acc[r] += sg.base[(int64_t)min(i0 + r, last) * sg.D + c] * y;
+                }
             }
-        } else {
-            for (int c = lane; c < sg.D; c += 64) acc += r[c] * g[c];
         }
-        acc = wave_sum(acc);
-        if (lane == 0) out[i] = acc;
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const float v = wave_sum(acc[r]);
+            const int i = i0 + r;
+            if (lane == 0 && i < row_end) {
+                const float da = i < n_stream ? v : 0.f;
+                out[i] = fused ? arow[i] * (da - dot) : da;
+            }
+        }
     }
 }
 
@@ -377,8 +416,25 @@ int attn_softmax_context_fwd(const mmqg_attn_values& v, const float* scores, int
     return check_launch("attn_softmax_context_fwd");
 }
 
+static int attn_context_bwd_impl(const mmqg_attn_values& v, const float* attn, int ld_a, const float* ctx, int ld_x,
+                                 const float* dctx, int ld_c, const float* dattn, int ld_da, float* dscores, int ld_ds,
+                                 hipStream_t s);
+
 int attn_context_bwd(const mmqg_attn_values& v, const float* attn, int ld_a, const float* dctx, int ld_c,
                      const float* dattn, int ld_da, float* dscores, int ld_ds, hipStream_t s) {
+    return attn_context_bwd_impl(v, attn, ld_a, nullptr, 0, dctx, ld_c, dattn, ld_da, dscores, ld_ds, s);
+}
+
+// the same with the forward's contexts at hand: ONE kernel (no separate softmax-Jacobian pass)
+int attn_context_bwd_fused(const mmqg_attn_values& v, const float* attn, int ld_a, const float* ctx, int ld_x,
+                           const float* dctx, int ld_c, float* dscores, int ld_ds, hipStream_t s) {
+    MMQG_REQUIRE(ctx && ld_x >= v.H + v.Da + v.Dv, "attn_context_bwd_fused: bad ctx");
+    return attn_context_bwd_impl(v, attn, ld_a, ctx, ld_x, dctx, ld_c, nullptr, 0, dscores, ld_ds, s);
+}
+
+static int attn_context_bwd_impl(const mmqg_attn_values& v, const float* attn, int ld_a, const float* ctx, int ld_x,
+                                 const float* dctx, int ld_c, const float* dattn, int ld_da, float* dscores, int ld_ds,
+                                 hipStream_t s) {
     MMQG_TRY(check_values(v, "attn_context_bwd"));
     if (v.B == 0) return 0;
     const int S = v.Lt + 2 * v.Lav;
@@ -389,14 +445,17 @@ int attn_context_bwd(const mmqg_attn_values& v, const float* attn, int ld_a, con
     k.v = v; k.dctx = dctx; k.ld_c = ld_c; k.dscores = dscores; k.ld_ds = ld_ds;
     k.blocks_text = ceil_div(v.Lt, kRowBlock);
     k.blocks_audio = ceil_div(v.Lav, kRowBlock);
-    const int blocks_video = ceil_div(v.Lav, kRowBlock);
+    k.blocks_video = ceil_div(v.Lav, kRowBlock);
     const bool g_ok = aligned16(dctx) && (ld_c % 4 == 0) && (v.H % 4 == 0) && (v.Da % 4 == 0);
     k.vec_text = g_ok && vec_ok(v.text, v.text_stride_b, v.H);
     k.vec_audio = g_ok && vec_ok(v.audio, v.audio_stride_b, v.Da);
     k.vec_video = g_ok && vec_ok(v.video, v.video_stride_b, v.Dv);
-    dim3 grid(k.blocks_text + k.blocks_audio + blocks_video, v.B);
+    dim3 grid((unsigned)((k.blocks_text + k.blocks_audio + k.blocks_video) * v.B));
+    const bool fused = ctx != nullptr && dattn == nullptr;
+    k.attn = fused ? attn : nullptr; k.ld_a = ld_a; k.ctx = fused ? ctx : nullptr; k.ld_x = ld_x;
     hipLaunchKernelGGL(attn_dweights_kernel, grid, dim3(256), 0, s, k);
     MMQG_TRY(check_launch("attn_dweights"));
+    if (fused) return 0;
     hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3(3, v.B), dim3(256), 0, s, v, attn, ld_a, dscores, ld_ds, dattn, ld_da);
     return check_launch("attn_softmax_bwd");
 }

@@ -72,6 +72,11 @@ int mmqg_attn_context_bwd(const mmqg_attn_values* v, const float* attn, int ld_a
     MMQG_REQUIRE(v, "mmqg_attn_context_bwd: null descriptor");
     return attn_context_bwd(*v, attn, ld_a, dctx, ld_c, dattn, ld_da, dscores, ld_ds, S(stream));
 }
+int mmqg_attn_context_bwd_fused(const mmqg_attn_values* v, const float* attn, int ld_a, const float* ctx, int ld_x,
+                                const float* dctx, int ld_c, float* dscores, int ld_ds, mmqg_stream stream) {
+    MMQG_REQUIRE(v, "mmqg_attn_context_bwd_fused: null descriptor");
+    return attn_context_bwd_fused(*v, attn, ld_a, ctx, ld_x, dctx, ld_c, dscores, ld_ds, S(stream));
+}
 int mmqg_attn_dvalues(int T, int B, int n_rows, int D, const float* attn, int64_t attn_stride_t, int ld_a, int seg_off,
                       const float* dctx, int64_t dctx_stride_t, int ld_c, int ctx_off, float* out,
                       int64_t out_stride_row, int64_t out_stride_b, int accumulate, mmqg_stream stream) {

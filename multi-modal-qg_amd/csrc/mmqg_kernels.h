@@ -85,6 +85,8 @@ int attn_softmax_context_fwd(const mmqg_attn_values& v, const float* scores, int
                              float* ctx, int ld_c, hipStream_t s);
 int attn_context_bwd(const mmqg_attn_values& v, const float* attn, int ld_a, const float* dctx, int ld_c,
                      const float* dattn, int ld_da, float* dscores, int ld_ds, hipStream_t s);
+int attn_context_bwd_fused(const mmqg_attn_values& v, const float* attn, int ld_a, const float* ctx, int ld_x,
+                           const float* dctx, int ld_c, float* dscores, int ld_ds, hipStream_t s);
 // dV[rows < n_rows] = sum_t attn[t][b][seg+row] * dctx[t][b][off..off+D)
 int attn_dvalues(int T, int B, int n_rows, int D, const float* attn, int64_t attn_stride_t, int ld_a, int seg_off,
                  const float* dctx, int64_t dctx_stride_t, int ld_c, int ctx_off, float* out, int64_t out_stride_row,

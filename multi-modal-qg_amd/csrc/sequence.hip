@@ -535,7 +535,9 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
             }
         }
         float* ds = g.dscores + (int64_t)t * B * ldD;
-        MMQG_TRY(attn_context_bwd(v, d.attn + (int64_t)t * B * ldS, ldS, g.dctx + (int64_t)t * B * C, C, nullptr, 0, ds, ldD, s));
+        // (one kernel: the softmax Jacobian's row dot is ctx(t) . dctx(t), the forward's saved context)
+        MMQG_TRY(attn_context_bwd_fused(v, d.attn + (int64_t)t * B * ldS, ldS, d.ctx + (int64_t)t * B * C, C,
+                                        g.dctx + (int64_t)t * B * C, C, ds, ldD, s));
         if (!fusedb)   // gradient of the query's h_top(t-1) half: feeds the top layer's recurrent gradient
             MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, S, ds, ldD, d.w_attn + E, Q, nullptr, 0, nullptr, 0, 0,
                               nullptr, nullptr, 1, g.dh + (int64_t)(L - 1) * BH, H, -1, s));

@@ -198,6 +198,41 @@ def test_attention_accepts_the_fused_value_layout(mm):
     close(ctx, ctx_w, what="fused ctx")
 
 
+@pytest.mark.parametrize("mask_mode,zero_past_len", [(0, 0), (1, 0), (0, 1)])
+def test_attention_backward_in_one_kernel_equals_the_oracle(mm, mask_mode, zero_past_len):
+    """mmqg_attn_context_bwd_fused: the softmax Jacobian's row dot sum_j a_j d(a)_j is taken as ctx . dctx (the
+    forward's saved context), so dscores comes out of ONE kernel; against the float64 oracle, also under the
+    intended masks and with the zero-padded rows skipped."""
+    _lib, ops = mm
+    B, Lt, Lav, H, Da, Dv = 6, 41, 13, 96, 24, 64
+    g = torch.Generator().manual_seed(17 + mask_mode)
+    scores, text, audio, video, text_len, av_len = _attn_case(g, B, Lt, Lav, H, Da, Dv)
+    if zero_past_len:                  # the caller's promise: rows past the valid lengths are zero
+        for b in range(B):
+            text[b, int(text_len[b]):] = 0
+            audio[b, int(av_len[b]):] = 0
+            video[b, int(av_len[b]):] = 0
+    leaves = [t.double().requires_grad_(True) for t in (scores, text, audio, video)]
+    attn_w, ctx_w = _attn_oracle(*leaves, text_len, av_len, mask_mode)
+    dctx = torch.randn(ctx_w.shape, generator=g)
+    (ctx_w * dctx.double()).sum().backward()
+    t_d, a_d, v_d, tl_d, al_d = dev(text), dev(audio), dev(video), dev(text_len), dev(av_len)
+    v = ops.make_attn_values(t_d, a_d, v_d, tl_d, al_d, mask_mode)
+    v.zero_past_len = zero_past_len
+    S, Cw = Lt + 2 * Lav, H + Da + Dv
+    sc, dc = dev(scores), dev(dctx)
+    attn, ctx = torch.empty(B, S, device="cuda"), torch.empty(B, Cw, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.mmqg_attn_softmax_context_fwd(C.byref(v), sc.data_ptr(), S, attn.data_ptr(), S, ctx.data_ptr(), Cw, ops._stream()))
+    ds = torch.full((B, S), 7.0, device="cuda")
+    _lib.check(lib.mmqg_attn_context_bwd_fused(C.byref(v), attn.data_ptr(), S, ctx.data_ptr(), Cw, dc.data_ptr(), Cw,
+                                               ds.data_ptr(), S, ops._stream()))
+    close(ds, leaves[0].grad.float(), what="dscores from the one-kernel backward")
+    ds2 = torch.empty(B, S, device="cuda")                       # and the two-kernel path on the same inputs
+    _lib.check(lib.mmqg_attn_context_bwd(C.byref(v), attn.data_ptr(), S, dc.data_ptr(), Cw, None, 0, ds2.data_ptr(), S, ops._stream()))
+    close(ds, ds2, tol=1e-5, what="one-kernel vs two-kernel dscores")
+
+
 def test_attention_dvalues_over_steps(mm):
     _lib, ops = mm
     T, B, Lt, Lav, H, Da, Dv = 6, 4, 11, 5, 32, 8, 16
