@@ -253,23 +253,28 @@ __global__ __launch_bounds__(256) void attn_dweights_kernel(AttnBwdK a) {
     const int n_stream = a.v.zero_past_len ? min(sg.L, sg.valid) : sg.L;      // rows past it are zero padding
     constexpr int kR = 4;
     const bool fused = a.attn != nullptr;
+    // fused path: dot = ctx . dctx, accumulated inside the first batch's column loop (the ctx loads travel with
+    // the first value rows instead of in front of them)
     float dot = 0.f;
-    const float* arow = nullptr;
-    if (fused) {
-        const float* cx = a.ctx + (int64_t)b * a.ld_x + sg.ctx_off;
-        for (int c = lane; c < sg.D; c += 64) dot += cx[c] * g[c];
-        dot = wave_sum(dot);
-        arow = a.attn + (int64_t)b * a.ld_a + sg.seg_off;
-    }
+    bool need_dot = fused;
+    const float* cx = fused ? a.ctx + (int64_t)b * a.ld_x + sg.ctx_off : nullptr;
+    const float* arow = fused ? a.attn + (int64_t)b * a.ld_a + sg.seg_off : nullptr;
     for (int i0 = blk * kRowBlock + wave * kR; i0 < row_end; i0 += 4 * kR) {
         float acc[kR];
 #pragma unroll
         for (int r = 0; r < kR; ++r) acc[r] = 0.f;
+        // the rows' attention weights (fused path) are requested together with the value rows: lane r holds row i0 + r's
+        float a_mine = 0.f;
+        if (fused && lane < kR && i0 + lane < row_end) a_mine = arow[i0 + lane];
         if (i0 < n_stream) {
             const int last = n_stream - 1;
             if (vec) {
                 for (int c = 4 * lane; c < sg.D; c += 256) {
                     const float4 y = *reinterpret_cast<const float4*>(g + c);
+                    if (need_dot) {
+                        const float4 z = *reinterpret_cast<const float4*>(cx + c);
+                        dot += z.x * y.x + z.y * y.y + z.z * y.z + z.w * y.w;
+                    }
                     float4 x[kR];
 #pragma unroll
                     for (int r = 0; r < kR; ++r)      // rows past the block / the stream: re-read a valid row, result unused
@@ -280,18 +285,23 @@ __global__ __launch_bounds__(256) void attn_dweights_kernel(AttnBwdK a) {
             } else {
                 for (int c = lane; c < sg.D; c += 64) {
                     const float y = g[c];
+                    if (need_dot) dot += cx[c] * y;
 #pragma unroll
                     for (int r = 0; r < kR; ++r) acc[r] += sg.base[(int64_t)min(i0 + r, last) * sg.D + c] * y;
                 }
             }
+        } else if (need_dot) {                      // nothing to stream for this wave: the dot still has to be formed
+            for (int c = lane; c < sg.D; c += 64) dot += cx[c] * g[c];
         }
+        if (need_dot) { dot = wave_sum(dot); need_dot = false; }
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
             const float v = wave_sum(acc[r]);
+            const float ai = __shfl(a_mine, r, 64);
             const int i = i0 + r;
             if (lane == 0 && i < row_end) {
                 const float da = i < n_stream ? v : 0.f;
-                out[i] = fused ? arow[i] * (da - dot) : da;
+                out[i] = fused ? ai * (da - dot) : da;
             }
         }
     }
