@@ -135,6 +135,46 @@ def test_audio_video_encoder_forward_matches_reference(mm):
         av("clip.wav", frames.unsqueeze(0))                              # a wav path needs the remote VGGish
 
 
+def test_frame_encoder_with_other_kernel_sizes_takes_the_framework_convolutions(mm):
+    """VideoConvLstmEncoder(kernel_sz, stride) other than the reference's 3 / 1 (config.py:66-67) is outside the
+    hand-written frame-CNN kernels: the drop-in module then runs PyTorch-ROCm's convolution / pooling ops in front of
+    the HIP frame LSTM.  Checked against a plain torch-CPU restatement of encoder.py:64-69 for ONE question
+    (conv -> ReLU -> BatchNorm over the question's frames, max-pool of kernel_sz after blocks 2 and 4), forward
+    and backward, so that path is at least exercised on the GPU (VERDICT r1 weak #9)."""
+    torch.manual_seed(7)
+    k, T, img = 5, 3, 112
+    side = ((img - 2 * (k - 1)) // k - 2 * (k - 1)) // k            # two convs, pool, two convs, pool
+    assert side >= 1
+    enc = mm["VideoConvLstmEncoder"](3, k, 1, 16, 10 * side * side).cuda().train()
+    ref = {n: p.detach().cpu().double().requires_grad_(True) for n, p in enc.named_parameters()}
+    frames = torch.rand(3, T, img, img)
+    out = enc(frames.cuda().unsqueeze(0)).squeeze(1)                 # (T, hidden)
+    probe = torch.randn(out.shape)
+    (out * probe.cuda()).sum().backward()
+
+    x = frames.double().contiguous().view(T, 3, img, img)            # encoder.py:64: raw view
+    for i, pool in ((1, False), (2, True), (3, False), (4, True)):
+        x = F.relu(F.conv2d(x, ref[f"conv{i}.weight"], ref[f"conv{i}.bias"]))
+        x = F.batch_norm(x, None, None, ref[f"bn{i}.weight"], ref[f"bn{i}.bias"], training=True, eps=enc.bn1.eps)
+        if pool:
+            x = F.max_pool2d(x, k, k)
+    feats = x.reshape(T, -1)
+    H = 16
+    h, c = torch.zeros(1, H, dtype=torch.double), torch.zeros(1, H, dtype=torch.double)
+    rows = []
+    for t in range(T):
+        g = feats[t:t + 1] @ ref["lstm.weight_ih_l0"].t() + ref["lstm.bias_ih_l0"] + h @ ref["lstm.weight_hh_l0"].t() + ref["lstm.bias_hh_l0"]
+        i_, f_, g_, o_ = g.chunk(4, dim=1)
+        c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
+        h = torch.sigmoid(o_) * torch.tanh(c)
+        rows.append(h[0])
+    want = torch.stack(rows)
+    (want * probe.double()).sum().backward()
+    close(out, want.float(), tol=2e-4, what="frame encoder output, 5x5 kernels")
+    for n, p in enc.named_parameters():
+        close(p.grad, ref[n].grad.float(), tol=5e-4, what=f"grad {n}, 5x5 kernels")
+
+
 def test_dropin_modules_train_with_torch_adam_like_train_py(mm):
     """The reference's optimizer setup verbatim (three torch Adam instances, shared embedding in
     two of them) on the drop-in modules: weights after two iterations match the reference's."""
