@@ -481,10 +481,19 @@ int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n
         const int split = pick_split(tiles, nk_min, bn == 64 ? 1024 : 768, 6, 8, 8);
         for (int i = 0; i < ng; ++i) b.p[i].split_k = split;
         b.split = split;
+        // MMQG_GROUP_MAX_WGS=n (experiments): at most n workgroups of this GEMM per CU, enforced by asking for unused
+        // dynamic LDS, so that the 8-wave kernels of a dependent chain on the other stream still find room on every CU
+        static const int max_wgs = env_int("MMQG_GROUP_MAX_WGS", 0);
+        const int static_lds = 2 * BK * ((128 + 4) + (bn + 4)) * 4;
+        size_t pad = 0;
+        if (max_wgs > 0) {
+            const int per = 160 * 1024 / (max_wgs + 1) + 1024;        // too big for max_wgs + 1 of them to share a CU
+            if (per > static_lds) pad = (size_t)(per - static_lds);
+        }
         if (bn == 64)
-            hipLaunchKernelGGL((gemm_f32_grouped_kernel<128, 64, BK, false, false>), dim3(tx, ty, ng * split), dim3(256), 0, s, b);
+            hipLaunchKernelGGL((gemm_f32_grouped_kernel<128, 64, BK, false, false>), dim3(tx, ty, ng * split), dim3(256), pad, s, b);
         else
-            hipLaunchKernelGGL((gemm_f32_grouped_kernel<128, 128, BK, false, false>), dim3(tx, ty, ng * split), dim3(256), 0, s, b);
+            hipLaunchKernelGGL((gemm_f32_grouped_kernel<128, 128, BK, false, false>), dim3(tx, ty, ng * split), dim3(256), pad, s, b);
         MMQG_TRY(check_launch("gemm_f32_grouped"));
     }
     return 0;
