@@ -77,7 +77,8 @@ def launcher_command(gpus: int, argv, port: int):
 
 
 def self_launch_needed(gpus: int, env) -> bool:
-    return gpus > 1 and "WORLD_SIZE" not in env
+    # MMQG_BENCH_FORCE_LAUNCH=1: go through the launcher for one GPU too (rehearses the N > 1 path on a one-GPU box)
+    return (gpus > 1 or env.get("MMQG_BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in env
 
 
 def self_launch(a, argv) -> int:

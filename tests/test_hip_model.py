@@ -720,3 +720,23 @@ def test_train_driver_on_a_tiny_corpus_in_the_reference_formats(mm, tmp_path, ca
     finally:
         for k, v in saved.items():
             setattr(Config, k, v)
+
+
+def test_bench_self_launch_runs_a_rank_through_rccl(mm):
+    """`python bench.py --gpus N` without WORLD_SIZE starts its own ranks.  Rehearsed here with the
+    one GPU of the test box: the launcher path is forced (MMQG_BENCH_FORCE_LAUNCH) and the single rank goes through the
+    RCCL exchange (MMQG_FORCE_DP); the parent must relay exactly one JSON line naming the backend and world size."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MMQG_BENCH_FORCE_LAUNCH="1", MMQG_FORCE_DP="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--kernel-iters", "5"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["world_size"] == 1 and "nccl" in d["config"]["collective_backend"]
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["roofline"]["achieved_beyond_mall"] > 0
