@@ -203,7 +203,7 @@ def kernel_rooflines(tr, w, iters):
         ops.gemm(0, 0, R, V, H, htop, H, out.weight, H, scratch, V, bias=out.bias)
     dtp = time_launches(proj, max(10, iters // 10))
     flops = 2.0 * R * H * V
-    mfma = {"kernel": "gemm_f32 (vocab projection fwd)", "bound": "mfma",
+    mfma = {"kernel": "gemm_nt_tile_kernel (vocab projection fwd: one 256 x BN tile per CU)", "bound": "mfma",
             "achieved": round(flops / dtp / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flops / dtp / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
             "flops_per_launch": flops, "us_per_launch": round(dtp * 1e6, 2)}

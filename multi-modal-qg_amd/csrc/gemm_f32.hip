@@ -366,6 +366,11 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
     MMQG_REQUIRE(lda >= (a_layout == MMQG_K_MAJOR ? K : M), "gemm_f32: lda too small");
     MMQG_REQUIRE(ldb >= (b_layout == MMQG_K_MAJOR ? K : N), "gemm_f32: ldb too small");
     MMQG_REQUIRE(ldc >= N, "gemm_f32: ldc too small");
+    // large k-major x k-major products with an overwritten output (the vocabulary projection): one big tile per CU
+    if (a_layout == MMQG_K_MAJOR && b_layout == MMQG_K_MAJOR && !A2 && !beta && split_k <= 1) {
+        const int rc = gemm_nt_tile(M, N, K, A, lda, B, ldb, bias, bias2, C, ldc, s);
+        if (rc <= 0) return rc;
+    }
     GemmArgs a;
     a.M = M; a.N = N; a.K = K; a.K2 = A2 ? K2 : 0;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;

@@ -13,6 +13,10 @@ namespace mmqg {
 int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
              const float* A2, int lda2, const float* B2, int ldb2, int K2, const float* bias, const float* bias2,
              int beta, float* C, int ldc, int split_k, hipStream_t s);
+// gemm_nt_tile.hip: C = A[M,K] * B[N,K]^T + bias + bias2 for large outputs with short K (the vocabulary projection), one
+// 256 x BN tile per CU; 0 = launched, 1 = not taken, < 0 = error
+int gemm_nt_tile(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
+                 const float* bias2, float* C, int ldc, hipStream_t s);
 // independent accumulating products (C += A*B) of one layout in as few launches as possible
 typedef mmqg_gemm_problem GemmProblem;
 int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n, hipStream_t s);

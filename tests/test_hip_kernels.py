@@ -46,6 +46,11 @@ GEMM_CASES = [
     (65, 33, 37, 1, 0, 1, 1, 1, False, 0, 1, 19),          # m-major A with k-major B, dual
     (130, 257, 300, 0, 0, 0, 0, 0, True, 0, 3, 0),
     (1, 10000, 512, 0, 0, 0, 0, 0, True, 0, -1, 0),        # batch-1 projection (the reference's own shape)
+    # shapes the one-tile-per-CU NT kernel takes (csrc/gemm_nt_tile.hip): the full vocabulary projection, ragged edges
+    # in both extents with padded leading dimensions, a short K, and a many-tiles-per-CU case
+    (1280, 10000, 512, 0, 0, 0, 0, 0, True, 0, -1, 0),
+    (1100, 7777, 96, 0, 0, 4, 8, 3, True, 0, 1, 0),
+    (2560, 12000, 128, 0, 0, 0, 0, 0, False, 0, -1, 0),
 ]
 
 

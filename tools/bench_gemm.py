@@ -22,6 +22,7 @@ def t(name, al, bl, M, N, K, iters=30):
 
 print("BIG_BK", os.environ.get("MMQG_GEMM_BIG_BK", "per layout"))
 t("vocab fwd  (NT)", 0, 0, 1280, 10000, 512)
+t("vocab fwd config5 (NT)", 0, 0, 2560, 50000, 1024, iters=10)
 t("vocab dgrad (NN)", 0, 1, 1280, 512, 10000)
 t("vocab wgrad (TN)", 1, 1, 10000, 512, 1280)
 t("dec wgrad W_ih0 (TN)", 1, 1, 2048, 1152, 1280)
