@@ -82,31 +82,15 @@ struct AttnFwdK {
     float* attn; int ld_a;
     float* ctx; int ld_c;
     int chunks_text, chunks_audio, chunks_video;   // column chunks per question and modality
+    int audio_chunk;                               // columns per audio chunk (32 when the main chunk is 64)
     int vec_text, vec_audio, vec_video;
 };
 
-template <int kChunk>   // value columns per workgroup: 256 threads = (kChunk/4) float4 column lanes x row groups
-__global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK a) {
+// One work item: (question b, modality, chunk of kChunk value columns): 256 threads = (kChunk/4) float4 column lanes x
+// row groups.
+template <int kChunk>
+__device__ __forceinline__ void attn_fwd_item(const AttnFwdK& a, int modality, int b, int chunk, float* w, float* red, float* sh) {
     constexpr int kLanes = kChunk / 4, kGroups = 256 / kLanes;
-    __shared__ float w[kMaxRows];
-    __shared__ __attribute__((aligned(16))) float red[kGroups * kChunk];
-    __shared__ float sh[8];
-
-    // Work items in dispatch order: every text item of the batch first (Lt rows each: the heavy ones), then the
-    // audio / video items (Lav rows).  Workgroups are handed to the CUs in launch order, so issuing the heavy
-    // items first spreads them evenly (2 per CU at config 2) and the light ones fill in behind them; with the
-    // natural (question, modality, chunk) order some CUs drew 3 heavy + 2 light items, 27% above the mean, and
-    // every CU streams at about the same rate (MI355X_MICROARCH.md: ~10 B/clk/CU from HBM).
-    int n = blockIdx.x, modality = 0, b, chunk;
-    const int text_items = a.v.B * a.chunks_text;
-    if (n < text_items) {
-        b = n / a.chunks_text; chunk = n - b * a.chunks_text;
-    } else {
-        n -= text_items;
-        const int per_q = a.chunks_audio + a.chunks_video;
-        b = n / per_q; chunk = n - b * per_q; modality = 1;
-        if (chunk >= a.chunks_audio) { chunk -= a.chunks_audio; modality = 2; }
-    }
     const Segment sg = pick_segment(a.v, modality, b);
     const bool vec = modality == 0 ? a.vec_text : (modality == 1 ? a.vec_audio : a.vec_video);
     const int tid = threadIdx.x;
@@ -213,6 +197,33 @@ __global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK 
             for (int r = 0; r < kGroups; ++r) s += red[r * kChunk + tid];
             a.ctx[(int64_t)b * a.ld_c + sg.ctx_off + c] = s * inv;
         }
+    }
+}
+
+// Work items in dispatch order: every text item of the batch first (Lt rows each: the heavy ones), then the video
+// items, then the audio items (Lav rows; audio in 32-column chunks).  Workgroups are handed to the CUs in launch order,
+// so at config 2 every CU draws 2 text items (72 KB each), 2 video items (26 KB) and 1 audio item (13 KB): 209 KB,
+// the same for all 256 CUs.  With the natural (question, modality, chunk) order some CUs drew 3 heavy + 2 light items,
+// 27% above the mean, and every CU streams at about the same rate (MI355X_MICROARCH.md: ~10 B/clk/CU from HBM).
+template <int kChunk>
+__global__ __launch_bounds__(256) void attn_softmax_context_fwd_kernel(AttnFwdK a) {
+    __shared__ float w[kMaxRows];
+    __shared__ __attribute__((aligned(16))) float red[1024];       // (256 / (chunk/4)) row groups x chunk columns
+    __shared__ float sh[8];
+    int n = blockIdx.x;
+    const int text_items = a.v.B * a.chunks_text, video_items = a.v.B * a.chunks_video;
+    if (n < text_items) {
+        const int b = n / a.chunks_text;
+        attn_fwd_item<kChunk>(a, 0, b, n - b * a.chunks_text, w, red, sh);
+    } else if (n - text_items < video_items) {
+        n -= text_items;
+        const int b = n / a.chunks_video;
+        attn_fwd_item<kChunk>(a, 2, b, n - b * a.chunks_video, w, red, sh);
+    } else {
+        n -= text_items + video_items;
+        const int b = n / a.chunks_audio;
+        if (a.audio_chunk == 32) attn_fwd_item<32>(a, 1, b, n - b * a.chunks_audio, w, red, sh);
+        else attn_fwd_item<kChunk>(a, 1, b, n - b * a.chunks_audio, w, red, sh);
     }
 }
 
@@ -413,7 +424,8 @@ int attn_softmax_context_fwd(const mmqg_attn_values& v, const float* scores, int
     k.v = v; k.scores = scores; k.ld_s = ld_s; k.attn = attn; k.ld_a = ld_a; k.ctx = ctx; k.ld_c = ld_c;
     static const int chunk = [] { const char* e = getenv("MMQG_ATTN_CHUNK"); return e ? atoi(e) : 64; }();
     k.chunks_text = ceil_div(v.H, chunk);
-    k.chunks_audio = ceil_div(v.Da, chunk);
+    k.audio_chunk = chunk == 64 ? 32 : chunk;
+    k.chunks_audio = ceil_div(v.Da, k.audio_chunk);
     k.chunks_video = ceil_div(v.Dv, chunk);
     k.vec_text = vec_ok(v.text, v.text_stride_b, v.H);
     k.vec_audio = vec_ok(v.audio, v.audio_stride_b, v.Da);
