@@ -462,6 +462,55 @@ def test_lstm_sequence_executor_forward_backward(mm, T, B, L, H, In, p):
             i += 1
 
 
+def test_persistent_time_loop_is_bitwise_repeatable_under_load(mm):
+    """The persistent forward hands h(t) between workgroups through write-through stores, sc1 loads and a fence-free
+    device-wide barrier (csrc/grid_barrier.h).  A stale read would show up as a run that differs from the others: the
+    same sequence is run 150 times — half of them beside a bandwidth-heavy GEMM stream on another queue (uneven
+    load, the regime in which broken hand-offs surface) — and every output must be bit-identical to the first run's,
+    which in turn matches the launch-per-diagonal path."""
+    _lib, ops = mm
+    lib = _lib.load()
+    T, B, L, H, In = 12, 64, 3, 256, 64
+    g = torch.Generator().manual_seed(99)
+    params = []
+    for l in range(L):
+        d = In if l == 0 else H
+        params += [torch.randn(4 * H, d, generator=g) * d ** -0.5, torch.randn(4 * H, H, generator=g) * H ** -0.5,
+                   torch.randn(4 * H, generator=g) * 0.3, torch.randn(4 * H, generator=g) * 0.3]
+    params = [dev(p) for p in params]
+    x, h0, c0 = dev(torch.randn(T, B, In, generator=g)), dev(torch.randn(L, B, H, generator=g) * 0.5), dev(torch.randn(L, B, H, generator=g) * 0.5)
+
+    def run():
+        with torch.no_grad():
+            y, hT, cT = ops.lstm_seq(x, h0, c0, params, 0.3, True, 4321)
+        return torch.cat((y.reshape(-1), hT.reshape(-1), cT.reshape(-1)))
+
+    before = lib.mmqg_persist_launch_count()
+    ops._stream_counter = __import__("itertools").count(7)          # the same dropout streams for every run
+    first = run()
+    assert lib.mmqg_persist_launch_count() == before + 1
+    side = torch.cuda.Stream()
+    a_big, b_big = torch.randn(4096, 4096, device="cuda"), torch.randn(4096, 4096, device="cuda")
+    for i in range(150):
+        if i % 2:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    a_big @ b_big
+        ops._stream_counter = __import__("itertools").count(7)
+        out = run()
+        assert torch.equal(out, first), f"run {i} differs from the first run (max abs diff {float((out - first).abs().max()):.3e})"
+    torch.cuda.synchronize()
+    # the launch-per-diagonal path on the same inputs (different summation order inside a product: not bitwise)
+    ops._stream_counter = __import__("itertools").count(7)
+    ws_bytes = lib.mmqg_lstm_seq_persist_ws_bytes
+    try:
+        lib.mmqg_lstm_seq_persist_ws_bytes = lambda *a: 0              # no workspace -> the executor takes the launches
+        ref = run()
+    finally:
+        lib.mmqg_lstm_seq_persist_ws_bytes = ws_bytes
+    close(first, ref, what="persistent vs launch-per-diagonal outputs")
+
+
 def test_transpose(mm):
     _lib, ops = mm
     g = torch.Generator().manual_seed(8)
