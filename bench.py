@@ -199,11 +199,16 @@ def kernel_rooflines(tr, w, iters):
     out = tr.dec.out_layer
     scratch = torch.empty(R, V, device=htop.device)
 
-    def proj(i):
-        ops.gemm(0, 0, R, V, H, htop, H, out.weight, H, scratch, V, bias=out.bias)
+    tiles = C.c_int32(0)
+
+    def proj(i):     # the launch the step makes: the product with the loss's row statistics in its epilogue
+        _lib.check(lib.mmqg_projection_fwd(R, V, H, htop.data_ptr(), H, out.weight.data_ptr(), H, out.bias.data_ptr(),
+                                           scratch.data_ptr(), V, tr.ws["proj_stats"].data_ptr(), tr._proj_stats_bytes,
+                                           C.byref(tiles), ops._stream()), "projection_fwd")
     dtp = time_launches(proj, max(10, iters // 10))
     flops = 2.0 * R * H * V
-    mfma = {"kernel": "gemm_nt_tile_kernel (vocab projection fwd: one 256 x BN tile per CU)", "bound": "mfma",
+    mfma = {"kernel": "gemm_nt_tile_kernel (vocab projection fwd: one 256 x BN tile per CU, loss statistics in the "
+                      "epilogue)" if tiles.value else "gemm_f32 (vocab projection fwd, generic tiles)", "bound": "mfma",
             "achieved": round(flops / dtp / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flops / dtp / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
             "flops_per_launch": flops, "us_per_launch": round(dtp * 1e6, 2)}

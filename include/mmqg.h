@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMQG_ABI_VERSION 3
+#define MMQG_ABI_VERSION 4
 #define MMQG_MAX_LAYERS 8
 
 typedef void* mmqg_stream; /* hipStream_t */
@@ -145,6 +145,20 @@ int mmqg_dropout_mask(float* out, int64_t n, float p, uint64_t seed, uint64_t st
 int mmqg_ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* row_weight,
                     int rows, int V, float* loss_rows, int64_t* argmax, float* dlogits, int ld_d,
                     mmqg_stream stream);
+/* The vocabulary projection of the teacher-forced step (decoder.py:106 nn.Linear(hidden, vocab) over all
+ * Td*B rows at once) with the loss's row statistics taken in the product's epilogue: when the one-tile-per-CU
+ * kernel serves the shape, stats[r][t] = {max, sum exp(x - max), first argmax (int bits), 0} over column tile t
+ * of row r and *stats_tiles (host int, written before the call returns) = tiles per row; otherwise the generic
+ * product runs and *stats_tiles = 0.  mmqg_ce_fwd_bwd_stats then combines the tiles instead of sweeping the
+ * logits for max and sum-exp (stats_tiles == 0: identical to mmqg_ce_fwd_bwd).  stats (nullable) holds
+ * mmqg_projection_stats_ws_bytes(rows, V) bytes, 16-byte aligned. */
+int64_t mmqg_projection_stats_ws_bytes(int rows, int V);
+int mmqg_projection_fwd(int rows, int V, int H, const float* h, int ldh, const float* W, int ldw,
+                        const float* bias, float* logits, int ld, float* stats, int64_t stats_bytes,
+                        int32_t* stats_tiles, mmqg_stream stream);
+int mmqg_ce_fwd_bwd_stats(const float* logits, int ld, const int64_t* target, const float* row_weight,
+                          int rows, int V, const float* stats, int stats_tiles, float* loss_rows,
+                          int64_t* argmax, float* dlogits, int ld_d, mmqg_stream stream);
 int mmqg_colsum_add(const float* X, int ld, int M, int N, float* out, mmqg_stream stream);
 int mmqg_reduce_sum(const float* x, int n, float* out, mmqg_stream stream);
 

@@ -113,6 +113,29 @@ int mmqg_ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const fl
                     float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, mmqg_stream stream) {
     return ce_fwd_bwd(logits, ld, target, row_weight, rows, V, loss_rows, argmax, dlogits, ld_d, S(stream));
 }
+int mmqg_ce_fwd_bwd_stats(const float* logits, int ld, const int64_t* target, const float* row_weight, int rows, int V,
+                          const float* stats, int stats_tiles, float* loss_rows, int64_t* argmax, float* dlogits, int ld_d,
+                          mmqg_stream stream) {
+    MMQG_REQUIRE(stats_tiles >= 0 && (stats_tiles == 0 || stats), "ce_fwd_bwd_stats: stats_tiles > 0 needs a stats buffer");
+    return ce_fwd_bwd(logits, ld, target, row_weight, rows, V, loss_rows, argmax, dlogits, ld_d, S(stream), stats,
+                      stats_tiles);
+}
+int64_t mmqg_projection_stats_ws_bytes(int rows, int V) { return rows > 0 && V > 0 ? gemm_nt_stats_bytes(rows, V) : 0; }
+int mmqg_projection_fwd(int rows, int V, int H, const float* h, int ldh, const float* W, int ldw, const float* bias,
+                        float* logits, int ld, float* stats, int64_t stats_bytes, int32_t* stats_tiles,
+                        mmqg_stream stream) {
+    MMQG_REQUIRE(stats_tiles, "projection_fwd: stats_tiles must point to an int");
+    *stats_tiles = 0;
+    if (rows <= 0 || V <= 0) return 0;
+    MMQG_REQUIRE(H > 0 && h && W && logits, "projection_fwd: null operand");
+    MMQG_REQUIRE(ldh >= H && ldw >= H && ld >= V, "projection_fwd: leading dimension too small");
+    const int rc = gemm_nt_tile(rows, V, H, h, ldh, W, ldw, bias, nullptr, logits, ld, S(stream), stats, stats_bytes,
+                                stats_tiles);
+    if (rc <= 0) return rc;
+    *stats_tiles = 0;
+    return gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, rows, V, H, h, ldh, W, ldw, nullptr, 0, nullptr, 0, 0, bias, nullptr, 0,
+                    logits, ld, 1, S(stream));
+}
 int mmqg_colsum_add(const float* X, int ld, int M, int N, float* out, mmqg_stream stream) {
     return colsum_add(X, ld, M, N, out, S(stream));
 }

@@ -57,12 +57,13 @@ struct NtArgs {
     const float* bias; const float* bias2;
     float* C; int ldc;
     int tiles_n, tiles;             // column tiles, total tiles
+    float4* stats;                  // nullable [M][tiles_n]: per row and column tile {max, sum exp(x - max), argmax index bits, 0}
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int NB, int W>
+template <int NB, int W, bool STATS>
 __global__ __launch_bounds__(64 * W, 2) void gemm_nt_tile_kernel(NtArgs p) {
     using G = Geo<NB, W>;
     constexpr int kBM = G::kBM, kStages = G::kStages, kSlots = G::kSlots, kLoads = G::kLoads;
@@ -135,20 +136,62 @@ __global__ __launch_bounds__(64 * W, 2) void gemm_nt_tile_kernel(NtArgs p) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int m = m0 + (2 * wave + r) * 16 + fi;
-            if (m >= p.M) continue;
-            float* crow = p.C + (int64_t)m * p.ldc;
+            const bool row_ok = m < p.M;
+            float* crow = p.C + (int64_t)min(m, p.M - 1) * p.ldc;
+            // bias first (in place), so that the row statistics below see the finished logits
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int n = n0 + nb * 16 + 4 * kq;
+                if (n + 3 < p.N) {
+                    if (p.bias) acc[r][nb] += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (p.bias2) acc[r][nb] += *reinterpret_cast<const f32x4*>(p.bias2 + n);
+                } else {
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < p.N) acc[r][nb][e] += (p.bias ? p.bias[n + e] : 0.f) + (p.bias2 ? p.bias2[n + e] : 0.f);
+                        else if (STATS) acc[r][nb][e] = -INFINITY;       // columns past N: out of the statistics, never stored
+                    }
+                }
+            }
+            if (STATS) {
+                // cross-entropy statistics of this row over the tile's columns (decoder.py:106 + train.py:174: the
+                // log-softmax needs max and sum-exp of the whole row; the loss kernel combines the column tiles'
+                // partial results instead of sweeping the logits twice more).  A row's columns sit in this lane and
+                // in the lanes +16, +32, +48.
+                float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = n0 + nb * 16 + 4 * kq + e;
+                        const float x = acc[r][nb][e];
+                        if (x > best || (x == best && n < bi)) { best = x; bi = n; }      // first maximum wins
+                    }
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const float ob = __shfl_xor(best, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                float sum = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sum += expf(acc[r][nb][e] - best);
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                if (kq == 0 && row_ok) p.stats[(int64_t)m * p.tiles_n + tn] = make_float4(best, sum, __int_as_float(bi), 0.f);
+            }
+            if (!row_ok) continue;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int n = n0 + nb * 16 + 4 * kq;
                 if (n >= p.N) continue;
-                f32x4 v = acc[r][nb];
+                const f32x4 v = acc[r][nb];
                 if (n + 3 < p.N) {
-                    if (p.bias) { const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n); v += bv; }
-                    if (p.bias2) { const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias2 + n); v += bv; }
                     *reinterpret_cast<f32x4*>(crow + n) = v;        // (non-temporal stores measured 3% slower)
                 } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e)
-                        crow[n + e] = v[e] + (p.bias ? p.bias[n + e] : 0.f) + (p.bias2 ? p.bias2[n + e] : 0.f);
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) crow[n + e] = v[e];
                 }
             }
         }
@@ -169,19 +212,24 @@ int device_cus() {
     return n;
 }
 
-template <int NB, int W>
-int launch_nt(const NtArgs& a, int grid, hipStream_t s) {
+template <int NB, int W, bool STATS>
+int launch_nt2(const NtArgs& a, int grid, hipStream_t s) {
     static int attr = 0;
     const int lds_bytes = Geo<NB, W>::kLdsBytes;
     if (attr == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_tile_kernel<NB, W>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_tile_kernel<NB, W, STATS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) (void)hipGetLastError();
         attr = e == hipSuccess ? 1 : -1;
     }
     if (attr < 0) return 1;
-    hipLaunchKernelGGL((gemm_nt_tile_kernel<NB, W>), dim3(grid), dim3(64 * W), (size_t)lds_bytes, s, a);
+    hipLaunchKernelGGL((gemm_nt_tile_kernel<NB, W, STATS>), dim3(grid), dim3(64 * W), (size_t)lds_bytes, s, a);
     return check_launch("gemm_nt_tile");
+}
+
+template <int NB, int W>
+int launch_nt(const NtArgs& a, int grid, hipStream_t s) {
+    return a.stats ? launch_nt2<NB, W, true>(a, grid, s) : launch_nt2<NB, W, false>(a, grid, s);
 }
 
 }  // namespace
@@ -189,8 +237,11 @@ int launch_nt(const NtArgs& a, int grid, hipStream_t s) {
 namespace mmqg {
 
 // 0 = launched, 1 = shape / operands not taken (the caller uses the generic tiled GEMM), < 0 = error
+int64_t gemm_nt_stats_bytes(int M, int N) { return (int64_t)M * ceil_div(N, 128) * 16; }
+
 int gemm_nt_tile(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
-                 const float* bias2, float* C, int ldc, hipStream_t s) {
+                 const float* bias2, float* C, int ldc, hipStream_t s, float* stats, int64_t stats_bytes, int* stats_tiles) {
+    if (stats_tiles) *stats_tiles = 0;
     static const bool off = [] { const char* e = getenv("MMQG_NO_NT_TILE"); return e && atoi(e) != 0; }();
     if (off) return 1;
     const int cus = device_cus();
@@ -214,23 +265,31 @@ int gemm_nt_tile(int M, int N, int K, const float* A, int lda, const float* B, i
         if (eff > best_eff) { best_eff = eff; best_nb = nb; }
     }
     if (best_nb == 0 || best_eff < 0.70) return 1;
-    NtArgs a{M, N, K, A, lda, B, ldb, bias, bias2, C, ldc, ceil_div(N, best_nb * 16), 0};
+    NtArgs a{M, N, K, A, lda, B, ldb, bias, bias2, C, ldc, ceil_div(N, best_nb * 16), 0, nullptr};
     a.tiles = tiles_m * a.tiles_n;
+    if (stats && stats_tiles && aligned16(stats) && stats_bytes >= (int64_t)M * a.tiles_n * 16) {
+        a.stats = reinterpret_cast<float4*>(stats);
+        *stats_tiles = a.tiles_n;
+    }
     const int grid = std::min(a.tiles, slots);
+    int rc;
     if (W == 8) {
         switch (best_nb) {
-            case 8: return launch_nt<8, 8>(a, grid, s);
-            case 10: return launch_nt<10, 8>(a, grid, s);
-            case 12: return launch_nt<12, 8>(a, grid, s);
-            default: return launch_nt<13, 8>(a, grid, s);
+            case 8: rc = launch_nt<8, 8>(a, grid, s); break;
+            case 10: rc = launch_nt<10, 8>(a, grid, s); break;
+            case 12: rc = launch_nt<12, 8>(a, grid, s); break;
+            default: rc = launch_nt<13, 8>(a, grid, s); break;
+        }
+    } else {
+        switch (best_nb) {
+            case 8: rc = launch_nt<8, 4>(a, grid, s); break;
+            case 10: rc = launch_nt<10, 4>(a, grid, s); break;
+            case 12: rc = launch_nt<12, 4>(a, grid, s); break;
+            default: rc = launch_nt<13, 4>(a, grid, s); break;
         }
     }
-    switch (best_nb) {
-        case 8: return launch_nt<8, 4>(a, grid, s);
-        case 10: return launch_nt<10, 4>(a, grid, s);
-        case 12: return launch_nt<12, 4>(a, grid, s);
-        default: return launch_nt<13, 4>(a, grid, s);
-    }
+    if (rc != 0 && stats_tiles) *stats_tiles = 0;
+    return rc;
 }
 
 }  // namespace mmqg

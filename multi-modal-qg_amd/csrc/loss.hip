@@ -10,20 +10,32 @@
 
 namespace {
 
+// stats (nullable): [rows][stats_tiles] partial {max, sum exp(x - max), argmax index bits} per column tile, written by the
+// projection GEMM's epilogue (gemm_nt_tile.hip): sweeps 1 and 2 then shrink to combining stats_tiles entries
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, int ld,
                                                          const int64_t* __restrict__ target,
                                                          const float* __restrict__ row_weight, int V,
                                                          float* __restrict__ loss_rows, int64_t* __restrict__ argmax,
-                                                         float* dlogits, int ld_d) {
+                                                         float* dlogits, int ld_d, const float4* __restrict__ stats,
+                                                         int stats_tiles) {
     __shared__ float shv[4];
     __shared__ int shi[4];
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (int64_t)r * ld;
     // sweep 1: max and the FIRST index that attains it (torch.argmax tie rule)
     float best = -INFINITY; int bi = 0x7fffffff;
-    for (int c = tid; c < V; c += 256) {
-        const float x = row[c];
-        if (x > best || (x == best && c < bi)) { best = x; bi = c; }
+    const float4* st = stats ? stats + (int64_t)r * stats_tiles : nullptr;
+    if (st) {
+        for (int c = tid; c < stats_tiles; c += 256) {
+            const float4 t = st[c];
+            const int ti = __float_as_int(t.z);
+            if (t.x > best || (t.x == best && ti < bi)) { best = t.x; bi = ti; }
+        }
+    } else {
+        for (int c = tid; c < V; c += 256) {
+            const float x = row[c];
+            if (x > best || (x == best && c < bi)) { best = x; bi = c; }
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -39,7 +51,11 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
     __syncthreads();
     // sweep 2: sum exp
     float part = 0.f;
-    for (int c = tid; c < V; c += 256) part += expf(row[c] - best);
+    if (st) {
+        for (int c = tid; c < stats_tiles; c += 256) { const float4 t = st[c]; part += t.y * expf(t.x - best); }
+    } else {
+        for (int c = tid; c < V; c += 256) part += expf(row[c] - best);
+    }
     part = wave_sum(part);
     if (lane == 0) shv[wave] = part;
     __syncthreads();
@@ -186,14 +202,16 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ dst, 
 namespace mmqg {
 
 int ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* row_weight, int rows, int V,
-               float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, hipStream_t s) {
+               float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, hipStream_t s, const float* stats,
+               int stats_tiles) {
     MMQG_REQUIRE(rows >= 0 && V > 0 && ld >= V, "ce_fwd_bwd: bad shape");
     if (rows == 0) return 0;
     MMQG_REQUIRE(logits, "ce_fwd_bwd: null logits");
     MMQG_REQUIRE(!dlogits || ld_d >= V, "ce_fwd_bwd: ld_d < V");
     MMQG_REQUIRE(target || (!loss_rows && !dlogits), "ce_fwd_bwd: loss/gradient requested without targets");
+    const float4* st = (stats && stats_tiles > 0) ? reinterpret_cast<const float4*>(stats) : nullptr;
     hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, s, logits, ld, target, row_weight, V, loss_rows,
-                       argmax, dlogits, ld_d);
+                       argmax, dlogits, ld_d, st, stats_tiles);
     return check_launch("ce_fwd_bwd");
 }
 

@@ -15,8 +15,12 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
              int beta, float* C, int ldc, int split_k, hipStream_t s);
 // gemm_nt_tile.hip: C = A[M,K] * B[N,K]^T + bias + bias2 for large outputs with short K (the vocabulary projection), one
 // 256 x BN tile per CU; 0 = launched, 1 = not taken, < 0 = error
+// stats (nullable, gemm_nt_stats_bytes(M, N) bytes): per row and column tile {max, sum exp(x - max), argmax index bits, 0}
+// for ce_fwd_bwd; *stats_tiles = column tiles written per row (0 = none)
+int64_t gemm_nt_stats_bytes(int M, int N);
 int gemm_nt_tile(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
-                 const float* bias2, float* C, int ldc, hipStream_t s);
+                 const float* bias2, float* C, int ldc, hipStream_t s, float* stats = nullptr, int64_t stats_bytes = 0,
+                 int* stats_tiles = nullptr);
 // independent accumulating products (C += A*B) of one layout in as few launches as possible
 typedef mmqg_gemm_problem GemmProblem;
 int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n, hipStream_t s);
@@ -102,7 +106,8 @@ int embedding_bwd(const float* dout, int ld, const int64_t* ids, float* dtable, 
 
 // ---- loss.hip -------------------------------------------------------------------------
 int ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const float* row_weight, int rows, int V,
-               float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, hipStream_t s);
+               float* loss_rows, int64_t* argmax, float* dlogits, int ld_d, hipStream_t s, const float* stats = nullptr,
+               int stats_tiles = 0);
 int colsum_add(const float* X, int ld, int M, int N, float* out, hipStream_t s);
 // out1 += column sums, out2 += the same sums (the two bias gradients of an LSTM layer); out2 may be null
 int colsum_add2(const float* X, int ld, int M, int N, float* out1, float* out2, hipStream_t s);

@@ -41,7 +41,6 @@ constexpr int kMaxWG = 256;
 constexpr int kThreads = 512;          // 8 waves: 2 per SIMD
 constexpr int kWaves = kThreads / 64;
 constexpr int kRows = 64;              // rows of the exchange layout (B <= 64)
-constexpr int kBatch = 16;             // 16-wide k-chunks per register batch (one batch per task + one shared batch in flight)
 constexpr int kLdsBudget = 160 * 1024 - 1024;   // dynamic LDS a workgroup may use (the kernel has a little static LDS too)
 
 // layer | unit << 2 | first row block << 14 | row blocks << 17 (0 row blocks = no task)

@@ -108,19 +108,40 @@ def dropout_mask(n: int, p: float, seed: int, stream_id: int, device, seed_offse
     return out
 
 
+def projection_fwd(h: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], want_stats: bool = True,
+                   ld: Optional[int] = None):
+    """logits = h @ weight.T + bias (decoder.py:106) -> (logits, stats, stats_tiles); stats_tiles == 0 when the
+    shape was served by the generic product (no loss statistics written).  ld: row pitch of the logits (>= V)."""
+    h, weight = _f32c(h), _f32c(weight)
+    rows, H = h.shape
+    V = weight.shape[0]
+    lib = _lib.load()
+    logits = torch.empty(rows, ld or V, device=h.device, dtype=torch.float32)[:, :V]
+    nbytes = int(lib.mmqg_projection_stats_ws_bytes(rows, V)) if want_stats else 0
+    stats = torch.empty(max(nbytes // 4, 4), device=h.device, dtype=torch.float32)
+    tiles = C.c_int32(0)
+    check(lib.mmqg_projection_fwd(rows, V, H, h.data_ptr(), h.stride(0), weight.data_ptr(), weight.stride(0), ptr(bias),
+                                  logits.data_ptr(), logits.stride(0), stats.data_ptr() if want_stats else None, nbytes,
+                                  C.byref(tiles), _stream()), "projection_fwd")
+    return logits, stats, tiles.value
+
+
 def ce_fwd_bwd(logits: torch.Tensor, target: Optional[torch.Tensor], row_weight: Optional[torch.Tensor],
-               want_grad: bool, in_place: bool = False):
-    """Returns (loss_rows, argmax, dlogits)."""
-    logits = _f32c(logits)
+               want_grad: bool, in_place: bool = False, stats: Optional[torch.Tensor] = None, stats_tiles: int = 0):
+    """Returns (loss_rows, argmax, dlogits).  stats/stats_tiles: the row statistics projection_fwd wrote."""
+    require_device(logits)
+    if logits.dtype != torch.float32 or logits.dim() != 2 or logits.stride(1) != 1:
+        logits = _f32c(logits)
     rows, V = logits.shape
     loss_rows = torch.empty(rows, device=logits.device, dtype=torch.float32) if target is not None else None
     argmax = torch.empty(rows, device=logits.device, dtype=torch.int64)
     dlogits = None
     if want_grad:
         dlogits = logits if in_place else torch.empty_like(logits)
-    check(_lib.load().mmqg_ce_fwd_bwd(logits.data_ptr(), logits.stride(0), ptr(target), ptr(row_weight), rows, V,
-                                      ptr(loss_rows), argmax.data_ptr(), ptr(dlogits),
-                                      dlogits.stride(0) if dlogits is not None else 0, _stream()), "ce_fwd_bwd")
+    check(_lib.load().mmqg_ce_fwd_bwd_stats(logits.data_ptr(), logits.stride(0), ptr(target), ptr(row_weight), rows, V,
+                                            ptr(stats) if stats_tiles else None, stats_tiles, ptr(loss_rows),
+                                            argmax.data_ptr(), ptr(dlogits),
+                                            dlogits.stride(0) if dlogits is not None else 0, _stream()), "ce_fwd_bwd")
     return loss_rows, argmax, dlogits
 
 

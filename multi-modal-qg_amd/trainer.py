@@ -194,6 +194,10 @@ class BatchedTrainer:
         w["gates_d"], w["hs_d"], w["cs_d"] = f(L, Td, B, 4 * H), f(L, Td + 1, B, H), f(L, Td + 1, B, H)
         w["hdrop_d"] = f(max(L - 1, 1), Td, B, H)
         w["logits"] = f(Td * B, V)
+        # loss statistics per row and column tile, written by the projection's epilogue (gemm_nt_tile.hip)
+        self._proj_stats_bytes = int(_lib.load().mmqg_projection_stats_ws_bytes(Td * B, V))
+        w["proj_stats"] = f(max(self._proj_stats_bytes // 4, 4))
+        self._proj_stats_tiles = 0
         w["loss_rows"] = f(Td * B)
         w["argmax"] = torch.zeros(Td * B, device=dev, dtype=torch.int64)
         w["loss"] = f(1)
@@ -501,7 +505,11 @@ class BatchedTrainer:
         self.d_dec.phase = 0
         htop = w["hs_d"][L - 1, 1:].reshape(self.Td * B, H)
         out = self.dec.out_layer
-        ops.gemm(K_MAJOR, K_MAJOR, self.Td * B, V, H, htop, H, out.weight, H, w["logits"], V, bias=out.bias)
+        tiles = C.c_int32(0)
+        check(lib.mmqg_projection_fwd(self.Td * B, V, H, htop.data_ptr(), H, out.weight.data_ptr(), H, out.bias.data_ptr(),
+                                      w["logits"].data_ptr(), V, w["proj_stats"].data_ptr(), self._proj_stats_bytes,
+                                      C.byref(tiles), s), "projection_fwd")
+        self._proj_stats_tiles = tiles.value     # a host decision that depends on the shape only: safe under graph capture
 
     def _loss_and_backward(self, part: str = "all"):
         """part 'all': the whole backward with its fork/join branches.  The distributed graph step
@@ -570,8 +578,9 @@ class BatchedTrainer:
 
     def _backward_decoder(self, lib, w, s, logits, out, htop, R):
         V, H = self.V, self.H
-        check(lib.mmqg_ce_fwd_bwd(logits.data_ptr(), V, w["target"].data_ptr(), w["row_w"].data_ptr(), R, V,
-                                  w["loss_rows"].data_ptr(), w["argmax"].data_ptr(), logits.data_ptr(), V, s), "ce_fwd_bwd")
+        check(lib.mmqg_ce_fwd_bwd_stats(logits.data_ptr(), V, w["target"].data_ptr(), w["row_w"].data_ptr(), R, V,
+                                        w["proj_stats"].data_ptr(), self._proj_stats_tiles, w["loss_rows"].data_ptr(),
+                                        w["argmax"].data_ptr(), logits.data_ptr(), V, s), "ce_fwd_bwd")
         # vocabulary projection backward (logits now holds dlogits): weight gradient on the side stream
         def vocab_side():            # weight gradient of the projection; the loss scalar is off the chain too
             check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), ops._stream()), "reduce_sum")

@@ -354,6 +354,44 @@ def test_cross_entropy_argmax_and_gradient(mm, rows, V):
     close(buf, ld.grad.float(), what="dlogits in place")
 
 
+@pytest.mark.parametrize("rows,V,H,ld,tiled", [(1280, 10000, 512, None, True), (1270, 7777, 96, 7780, True),
+                                                 (2560, 12000, 128, 12032, True), (1270, 7777, 96, None, False),
+                                                 (80, 10000, 512, None, False)])
+def test_projection_with_loss_statistics_equals_the_three_sweep_loss(mm, rows, V, H, ld, tiled):
+    """decoder.py:106 + train.py:174: the projection's epilogue hands max / sum-exp / first argmax per column tile to
+    the loss kernel; loss, argmax (ties: first index, within a lane, across lanes and across tiles) and gradient must
+    equal the kernel that sweeps the logits itself, and the float64 loss of the same logits."""
+    _lib, ops = mm
+    g = torch.Generator().manual_seed(rows * 7 + V)
+    h = torch.randn(rows, H, generator=g)
+    W = torch.randn(V, H, generator=g) / H ** 0.5
+    b = torch.randn(V, generator=g) * 0.1
+    far = min(V - 1, 5 + 16 * 13 * 3)
+    W[5] = W[9] = W[6] = W[far] = 6 * h[1] / h[1].norm()            # one maximum, four times, in row 1
+    b[5] = b[9] = b[6] = b[far] = 0.25
+    target = torch.randint(0, V, (rows,), generator=g)
+    wgt = torch.rand(rows, generator=g)
+    wgt[0] = 0.0
+    logits, stats, tiles = ops.projection_fwd(dev(h), dev(W), dev(b), ld=ld)
+    assert (tiles > 0) == tiled          # (an odd row pitch or a small product goes to the generic kernel: no statistics)
+    want_logits = h.double() @ W.double().T + b.double()
+    close(logits, want_logits.float(), what="projection logits")
+    keep = logits.clone()
+    loss3, arg3, d3 = ops.ce_fwd_bwd(keep.clone(), dev(target), dev(wgt), want_grad=True)
+    loss1, arg1, d1 = ops.ce_fwd_bwd(logits, dev(target), dev(wgt), want_grad=True, in_place=True, stats=stats,
+                                     stats_tiles=tiles)
+    assert d1.data_ptr() == logits.data_ptr()
+    assert torch.equal(arg1, arg3) and int(arg1[1]) == 5
+    assert torch.equal(arg1.cpu(), torch.argmax(keep.cpu(), dim=1))
+    ld = keep.cpu().double().requires_grad_(True)
+    ce = torch.nn.functional.cross_entropy(ld, target, reduction="none") * wgt.double()
+    ce.sum().backward()
+    close(loss1, ce.float(), tol=2e-6, what="loss rows from statistics")
+    close(d1, ld.grad.float(), tol=2e-6, what="dlogits from statistics")
+    close(loss1, loss3, tol=2e-6, what="loss rows, one sweep against three")
+    close(d1, d3, tol=2e-6, what="dlogits, one sweep against three")
+
+
 def test_colsum_and_reduce_sum(mm):
     _lib, ops = mm
     g = torch.Generator().manual_seed(1)

@@ -32,12 +32,18 @@ def s():
 
 def vocab_fwd():
     htop = ws["hs_d"][L - 1, 1:].reshape(R, H)
-    ops.gemm(0, 0, R, V, H, htop, H, tr.dec.out_layer.weight, H, ws["logits"], V, bias=tr.dec.out_layer.bias)
+    tiles = C.c_int32(0)
+    out = tr.dec.out_layer
+    check(lib.mmqg_projection_fwd(R, V, H, htop.data_ptr(), H, out.weight.data_ptr(), H, out.bias.data_ptr(),
+                                  ws["logits"].data_ptr(), V, ws["proj_stats"].data_ptr(), tr._proj_stats_bytes,
+                                  C.byref(tiles), s()))
+    tr._proj_stats_tiles = tiles.value
 
 
 def ce():
-    check(lib.mmqg_ce_fwd_bwd(ws["logits"].data_ptr(), V, ws["target"].data_ptr(), ws["row_w"].data_ptr(), R, V,
-                              ws["loss_rows"].data_ptr(), ws["argmax"].data_ptr(), ws["logits"].data_ptr(), V, s()))
+    check(lib.mmqg_ce_fwd_bwd_stats(ws["logits"].data_ptr(), V, ws["target"].data_ptr(), ws["row_w"].data_ptr(), R, V,
+                                    ws["proj_stats"].data_ptr(), tr._proj_stats_tiles, ws["loss_rows"].data_ptr(),
+                                    ws["argmax"].data_ptr(), ws["logits"].data_ptr(), V, s()))
 
 
 def vocab_bwd():
