@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA (spec)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md; the 5 PF headline figure is 2:1 sparse)
 MALL_BYTES = 256 << 20         # Infinity Cache
 
 
@@ -207,11 +208,23 @@ def kernel_rooflines(tr, w, iters):
                                            C.byref(tiles), ops._stream()), "projection_fwd")
     dtp = time_launches(proj, max(10, iters // 10))
     flops = 2.0 * R * H * V
-    mfma = {"kernel": "gemm_nt_tile_kernel (vocab projection fwd: one 256 x BN tile per CU, loss statistics in the "
-                      "epilogue)" if tiles.value else "gemm_f32 (vocab projection fwd, generic tiles)", "bound": "mfma",
-            "achieved": round(flops / dtp / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / dtp / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-            "flops_per_launch": flops, "us_per_launch": round(dtp * 1e6, 2)}
+    which = int(lib.mmqg_projection_last_kernel())
+    tf = flops / dtp / 1e12
+    if which == 2:
+        # fp32-exact operands as three bf16 pieces each, six bf16 MFMAs per fp32 product: the matrix-core ceiling of
+        # the method is the dense bf16 peak / 6; the fraction of the fp32 MFMA peak is given beside it
+        peak = MFMA_BF16_PEAK_TFLOPS / 6.0
+        mfma = {"kernel": "gemm_x3pp_kernel<NT, stats> (vocab projection fwd: split-bf16, 256 x 128 tiles, loss "
+                          "statistics in the epilogue)", "bound": "mfma", "achieved": round(tf, 2),
+                "peak": round(peak, 1), "unit": "TFLOP/s (fp32-equivalent: 2 M N K per launch)", "frac": round(tf / peak, 4),
+                "peak_basis": "dense bf16 MFMA 2500 TFLOP/s / 6 piece products per fp32 product",
+                "executed_bf16_tflops": round(6 * tf, 1), "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+    else:
+        mfma = {"kernel": "gemm_nt_tile_kernel (vocab projection fwd: one 256 x BN tile per CU, loss statistics in the "
+                          "epilogue)" if which == 1 else "gemm_f32 (vocab projection fwd, generic tiles)", "bound": "mfma",
+                "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+    mfma.update({"traffic": None, "flops_per_launch": flops, "us_per_launch": round(dtp * 1e6, 2)})
     return roof, mfma
 
 
@@ -339,6 +352,8 @@ def main(argv=None):
                       "vocab": w.vocab, "emb_dim": w.emb_dim, "hidden": w.hidden, "layers": w.layers,
                       "attn_widths": [w.text_max_length, w.av_max_length], "dropout": w.dropout,
                       "parallelism": f"dp{world}", "hipgraph": bool(tr.use_graph),
+                      "large_gemms": ("fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulation"
+                                      if os.environ.get("MMQG_GEMM_X3", "1") != "0" else "fp32 MFMA"),
                       "skip_zero_value_rows": bool(a.skip_zero_rows),
                       "world_size": torch.distributed.get_world_size() if use_pg else 1,
                       "collective_backend": backend},

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMQG_ABI_VERSION 4
+#define MMQG_ABI_VERSION 5
 #define MMQG_MAX_LAYERS 8
 
 typedef void* mmqg_stream; /* hipStream_t */
@@ -153,6 +153,9 @@ int mmqg_ce_fwd_bwd(const float* logits, int ld, const int64_t* target, const fl
  * logits for max and sum-exp (stats_tiles == 0: identical to mmqg_ce_fwd_bwd).  stats (nullable) holds
  * mmqg_projection_stats_ws_bytes(rows, V) bytes, 16-byte aligned. */
 int64_t mmqg_projection_stats_ws_bytes(int rows, int V);
+/* which kernel the last mmqg_projection_fwd call took: 0 generic tiled fp32 MFMA, 1 one-tile-per-CU fp32 MFMA,
+ * 2 split-bf16 (fp32-exact operands as three bf16 pieces each, six bf16 MFMAs per product, fp32 accumulation) */
+int mmqg_projection_last_kernel(void);
 int mmqg_projection_fwd(int rows, int V, int H, const float* h, int ldh, const float* W, int ldw,
                         const float* bias, float* logits, int ld, float* stats, int64_t stats_bytes,
                         int32_t* stats_tiles, mmqg_stream stream);

@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmqg_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LAYERS = 8
 
 K_MAJOR, MN_MAJOR = 0, 1
@@ -159,6 +159,7 @@ SIGNATURES = {
     "mmqg_ce_fwd_bwd": [c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_i, c_f],
     "mmqg_ce_fwd_bwd_stats": [c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_i, c_f, c_f, c_f, c_i, c_f],
     "mmqg_projection_stats_ws_bytes": [c_i, c_i],
+    "mmqg_projection_last_kernel": [],
     "mmqg_projection_fwd": [c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_f, c_i64, C.POINTER(C.c_int32), c_f],
     "mmqg_colsum_add": [c_f, c_i, c_i, c_i, c_f, c_f],
     "mmqg_reduce_sum": [c_f, c_i, c_f, c_f],

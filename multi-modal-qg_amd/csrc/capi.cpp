@@ -120,6 +120,8 @@ int mmqg_ce_fwd_bwd_stats(const float* logits, int ld, const int64_t* target, co
     return ce_fwd_bwd(logits, ld, target, row_weight, rows, V, loss_rows, argmax, dlogits, ld_d, S(stream), stats,
                       stats_tiles);
 }
+static int g_projection_kernel = 0;
+int mmqg_projection_last_kernel(void) { return g_projection_kernel; }
 int64_t mmqg_projection_stats_ws_bytes(int rows, int V) { return rows > 0 && V > 0 ? gemm_nt_stats_bytes(rows, V) : 0; }
 int mmqg_projection_fwd(int rows, int V, int H, const float* h, int ldh, const float* W, int ldw, const float* bias,
                         float* logits, int ld, float* stats, int64_t stats_bytes, int32_t* stats_tiles,
@@ -129,9 +131,12 @@ int mmqg_projection_fwd(int rows, int V, int H, const float* h, int ldh, const f
     if (rows <= 0 || V <= 0) return 0;
     MMQG_REQUIRE(H > 0 && h && W && logits, "projection_fwd: null operand");
     MMQG_REQUIRE(ldh >= H && ldw >= H && ld >= V, "projection_fwd: leading dimension too small");
-    const int rc = gemm_nt_tile(rows, V, H, h, ldh, W, ldw, bias, nullptr, logits, ld, S(stream), stats, stats_bytes,
-                                stats_tiles);
-    if (rc <= 0) return rc;
+    // the split-bf16 kernel first (fp32-exact operands on the bf16 matrix cores), then the fp32 one-tile-per-CU kernel
+    int rc = gemm_x3_projection(rows, V, H, h, ldh, W, ldw, bias, logits, ld, stats, stats_bytes, stats_tiles, S(stream));
+    if (rc <= 0) { g_projection_kernel = 2; return rc; }
+    rc = gemm_nt_tile(rows, V, H, h, ldh, W, ldw, bias, nullptr, logits, ld, S(stream), stats, stats_bytes, stats_tiles);
+    if (rc <= 0) { g_projection_kernel = 1; return rc; }
+    g_projection_kernel = 0;
     *stats_tiles = 0;
     return gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, rows, V, H, h, ldh, W, ldw, nullptr, 0, nullptr, 0, 0, bias, nullptr, 0,
                     logits, ld, 1, S(stream));

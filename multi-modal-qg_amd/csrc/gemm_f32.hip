@@ -371,6 +371,12 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
         const int rc = gemm_nt_tile(M, N, K, A, lda, B, ldb, bias, bias2, C, ldc, s);
         if (rc <= 0) return rc;
     }
+    // large single products: the split-bf16 kernel (fp32-exact operands on the bf16 matrix cores, gemm_x3.hip)
+    if (!A2 && !(a_layout == MMQG_MN_MAJOR && b_layout == MMQG_K_MAJOR) && gemm_x3_wants(M, N, K)) {
+        const GemmProblem q{M, N, K, A, lda, B, ldb, C, ldc, beta ? 1 : 0};
+        const int rc = gemm_x3_grouped(a_layout, b_layout, &q, &bias, &bias2, 1, s);
+        if (rc <= 0) return rc;
+    }
     GemmArgs a;
     a.M = M; a.N = N; a.K = K; a.K2 = A2 ? K2 : 0;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
@@ -448,6 +454,15 @@ int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n
     bool ok = !no_group && n >= 2 && a_layout == MMQG_MN_MAJOR && b_layout == MMQG_MN_MAJOR;
     for (int i = 0; i < n && ok; ++i)
         ok = probs[i].beta == 1 && probs[i].M >= 128 && probs[i].N >= 128 && probs[i].K >= 1 && probs[i].A && probs[i].B && probs[i].C;
+    // groups of large products: the split-bf16 kernel takes every layout pair it has and any beta
+    if (n >= 1 && !(a_layout == MMQG_MN_MAJOR && b_layout == MMQG_K_MAJOR)) {
+        bool all = true;
+        for (int i = 0; i < n && all; ++i) all = probs[i].A && probs[i].B && probs[i].C && gemm_x3_wants(probs[i].M, probs[i].N, probs[i].K);
+        if (all) {
+            const int rc = gemm_x3_grouped(a_layout, b_layout, probs, nullptr, nullptr, n, s);
+            if (rc <= 0) return rc;
+        }
+    }
     if (!ok) {
         for (int i = 0; i < n; ++i) {
             const GemmProblem& q = probs[i];
