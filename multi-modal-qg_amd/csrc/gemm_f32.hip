@@ -454,13 +454,20 @@ int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n
     bool ok = !no_group && n >= 2 && a_layout == MMQG_MN_MAJOR && b_layout == MMQG_MN_MAJOR;
     for (int i = 0; i < n && ok; ++i)
         ok = probs[i].beta == 1 && probs[i].M >= 128 && probs[i].N >= 128 && probs[i].K >= 1 && probs[i].A && probs[i].B && probs[i].C;
-    // groups of large products: the split-bf16 kernel takes every layout pair it has and any beta
+    // the large products of a group go to the split-bf16 kernel (every layout pair it has, any beta) in one launch;
+    // what is left (short K, narrow outputs) continues below
     if (n >= 1 && !(a_layout == MMQG_MN_MAJOR && b_layout == MMQG_K_MAJOR)) {
-        bool all = true;
-        for (int i = 0; i < n && all; ++i) all = probs[i].A && probs[i].B && probs[i].C && gemm_x3_wants(probs[i].M, probs[i].N, probs[i].K);
-        if (all) {
-            const int rc = gemm_x3_grouped(a_layout, b_layout, probs, nullptr, nullptr, n, s);
-            if (rc <= 0) return rc;
+        GemmProblem big[2 * MMQG_MAX_LAYERS + 4], rest[2 * MMQG_MAX_LAYERS + 4];
+        int nb = 0, nr = 0;
+        const int cap = 2 * MMQG_MAX_LAYERS + 4;
+        for (int i = 0; i < n && n <= cap; ++i) {
+            const bool want = probs[i].A && probs[i].B && probs[i].C && gemm_x3_wants(probs[i].M, probs[i].N, probs[i].K);
+            if (want) big[nb++] = probs[i]; else rest[nr++] = probs[i];
+        }
+        if (nb > 0) {
+            const int rc = gemm_x3_grouped(a_layout, b_layout, big, nullptr, nullptr, nb, s);
+            if (rc < 0) return rc;
+            if (rc == 0) return nr > 0 ? gemm_f32_grouped(a_layout, b_layout, rest, nr, s) : 0;
         }
     }
     if (!ok) {

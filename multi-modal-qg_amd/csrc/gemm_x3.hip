@@ -251,8 +251,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(X3Batch b) {
 // at the same time by construction, with one barrier per phase and two phases per chunk:
 //     phase 2k   : group 0 products(chunk k)      | group 1 stages A(chunk k+1), fetches A(chunk k+3)
 //     phase 2k+1 : group 0 stages B(chunk k+1),.. | group 1 products(chunk k)
-// Rows are 64 bytes (32 bf16), the 16-byte slots of a row XOR-swizzled by (row >> 2) & 3: the ds_read_b128 lane groups
-// (MI355X_MICROARCH.md, LDS) then hit 16 distinct bank quads.  2 x 3 planes x 384 rows x 64 B = 144 KB: one workgroup
+// Rows are 64 bytes (32 bf16), the 16-byte slots of a row XOR-swizzled (swz() below): the ds_read_b128 lane groups
+// (MI355X_MICROARCH.md, LDS) then hit 16 distinct bank quads and the staging stores are conflict-free too.  2 x 3 planes x 384 rows x 64 B = 144 KB: one workgroup
 // per CU, raw operands of two chunks in flight per staging thread.
 constexpr int kPM = 256, kPN = 128;
 constexpr int kPRows = kPM + kPN;
@@ -260,7 +260,10 @@ constexpr int kPPlane = kPRows * 64;
 constexpr int kPBuf = 3 * kPPlane;                 // 73,728
 constexpr int kPLds = 2 * kPBuf;                   // 147,456
 
-__device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+// slot ^ f(row), f = ((row >> 2) ^ (row >> 1)) & 3: conflict-free for the fragment reads (every 16-lane group of a
+// ds_read_b128 meets four rows of each residue mod 4, and f is distinct on them) AND for both staging patterns'
+// ds_write_b128 (8-lane groups = 4 rows x 2 halves, or 8 consecutive rows: same-parity rows get distinct f)
+__device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ (((row >> 2) ^ (row >> 1)) & 3)) << 4); }
 
 template <bool AK, bool BKM, bool STATS>
 __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
@@ -436,8 +439,8 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
 
     if (STATS) {
         // Projection with loss statistics (decoder.py:106 + train.py:174; one k slice, no beta): the tile goes through
-        // the LDS (free now) so that a thread owns half a row — 64 consecutive columns: bias, the row's max / first
-        // argmax / sum-exp over the tile's 128 columns (one shuffle with the partner lane), and 16-byte stores.
+        // the LDS (free now) and comes back row by row: bias, the row's max / first argmax / sum-exp over the tile's
+        // 128 columns, and fully coalesced 16-byte stores.
         constexpr int kTS = 132;                             // floats per staged row (128 + 4: ds_read_b128-aligned)
         float* T = reinterpret_cast<float*>(smem);
         __syncthreads();                                     // every wave is done reading the operand buffers
@@ -451,43 +454,43 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
                     T[r * kTS + wc * 64 + j * 32 + (lane & 31)] = acc[i][j][e];
                 }
         __syncthreads();
-        const int row = tid >> 1, hf = tid & 1;
-        const int m = m0 + row, nb = n0 + hf * 64;
-        float best = -INFINITY, sum = 0.f;
-        int bi = 0x7fffffff;
-        f32x4 v[16];
+        // a half-wave owns a row at a time: lane l of it holds columns 4 l .. 4 l + 3 (512 contiguous bytes per row and
+        // store), the row's statistics are reduced over the 32 lanes
+        const int l32 = tid & 31, hw = tid >> 5;
+        const int n = n0 + 4 * l32;
+        f32x4 bias4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            v[q] = *reinterpret_cast<const f32x4*>(T + row * kTS + hf * 64 + 4 * q);
-            const int n = nb + 4 * q;
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) bias4[e] = (p.bias ? p.bias[n + e] : 0.f) + (p.bias2 ? p.bias2[n + e] : 0.f);
+        const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && n + 3 < p.N;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = hw + 16 * it;
+            const int m = m0 + row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(T + row * kTS + 4 * l32) + bias4;
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (n + e < p.N) v[q][e] += (p.bias ? p.bias[n + e] : 0.f) + (p.bias2 ? p.bias2[n + e] : 0.f);
-                else v[q][e] = -INFINITY;                    // past N: out of the statistics, never stored
-                if (v[q][e] > best) { best = v[q][e]; bi = n + e; }      // ascending n: the first maximum stays
+                if (n + e >= p.N) v[e] = -INFINITY;          // past N: out of the statistics, never stored
+                if (v[e] > best) { best = v[e]; bi = n + e; }            // ascending n: the first maximum stays
             }
-        }
-        {
-            const float ob = __shfl_xor(best, 1, 64);
-            const int oi = __shfl_xor(bi, 1, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
+            for (int off = 16; off >= 1; off >>= 1) {
+                const float ob = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            float sum = expf(v[0] - best) + expf(v[1] - best) + expf(v[2] - best) + expf(v[3] - best);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sum += expf(v[q][e] - best);
-        sum += __shfl_xor(sum, 1, 64);
-        if (m < p.M) {
-            if (hf == 0) p.stats[(int64_t)m * p.tiles_n + tn] = make_float4(best, sum, __int_as_float(bi), 0.f);
-            float* crow = p.C + (int64_t)m * p.ldc;
-            const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int n = nb + 4 * q;
-                if (n + 3 < p.N && vec_ok) *reinterpret_cast<f32x4*>(crow + n) = v[q];
+            for (int off = 16; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+            if (m < p.M) {
+                if (l32 == 0) p.stats[(int64_t)m * p.tiles_n + tn] = make_float4(best, sum, __int_as_float(bi), 0.f);
+                float* crow = p.C + (int64_t)m * p.ldc;
+                if (vec_ok) *reinterpret_cast<f32x4*>(crow + n) = v;
                 else
                     for (int e = 0; e < 4; ++e)
-                        if (n + e < p.N) crow[n + e] = v[q][e];
+                        if (n + e < p.N) crow[n + e] = v[e];
             }
         }
         return;
@@ -590,6 +593,17 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
     if (a_layout == MMQG_MN_MAJOR && b_layout == MMQG_K_MAJOR) return 1;       // no caller; not instantiated
     static const bool pp = [] { const char* e = getenv("MMQG_X3_PP"); return !e || atoi(e) != 0; }();
     const int tile_m = pp ? kPM : kTile, tile_n = pp ? kPN : kTile;
+    // every problem is checked BEFORE anything is launched: "not taken" must leave all outputs untouched
+    for (int i = 0; i < n; ++i) {
+        const GemmProblem& q = probs[i];
+        if (q.M <= 0 || q.N <= 0 || q.K < 4) return 1;
+        // per-thread byte offsets are 32-bit; k-major operands are read by 16-byte loads
+        if ((int64_t)q.M * q.K >= (1ll << 29) || (int64_t)q.N * q.K >= (1ll << 29)) return 1;
+        if ((a_layout == MMQG_K_MAJOR ? (int64_t)q.M * q.lda : (int64_t)q.K * q.lda) >= (1ll << 29)) return 1;
+        if ((b_layout == MMQG_K_MAJOR ? (int64_t)q.N * q.ldb : (int64_t)q.K * q.ldb) >= (1ll << 29)) return 1;
+        if (a_layout == MMQG_K_MAJOR && !((q.lda % 4 == 0) && (q.K % 4 == 0) && aligned16p(q.A))) return 1;
+        if (b_layout == MMQG_K_MAJOR && !((q.ldb % 4 == 0) && (q.K % 4 == 0) && aligned16p(q.B))) return 1;
+    }
     for (int g0 = 0; g0 < n; g0 += kMaxProblems) {
         const int ng = std::min(kMaxProblems, n - g0);
         X3Batch b{};
@@ -597,13 +611,6 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
         int64_t tiles_total = 0;
         for (int i = 0; i < ng; ++i) {
             const GemmProblem& q = probs[g0 + i];
-            if (q.M <= 0 || q.N <= 0 || q.K < 4) return 1;
-            // per-thread byte offsets are 32-bit; k-major operands are read by 16-byte loads
-            if ((int64_t)q.M * q.K >= (1ll << 29) || (int64_t)q.N * q.K >= (1ll << 29)) return 1;
-            if ((a_layout == MMQG_K_MAJOR ? (int64_t)q.M * q.lda : (int64_t)q.K * q.lda) >= (1ll << 29)) return 1;
-            if ((b_layout == MMQG_K_MAJOR ? (int64_t)q.N * q.ldb : (int64_t)q.K * q.ldb) >= (1ll << 29)) return 1;
-            if (a_layout == MMQG_K_MAJOR && !((q.lda % 4 == 0) && (q.K % 4 == 0) && aligned16p(q.A))) return 1;
-            if (b_layout == MMQG_K_MAJOR && !((q.ldb % 4 == 0) && (q.K % 4 == 0) && aligned16p(q.B))) return 1;
             tiles_total += (int64_t)ceil_div(q.M, tile_m) * ceil_div(q.N, tile_n);
         }
         // k slices: fill the chip's workgroup slots, keep >= 8 chunks per slice
@@ -638,6 +645,7 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
             if (a_layout == MMQG_K_MAJOR && b_layout == MMQG_K_MAJOR) rc = launch_pp<true, true>(b, wg, s);
             else if (a_layout == MMQG_K_MAJOR) rc = launch_pp<true, false>(b, wg, s);
             else rc = launch_pp<false, false>(b, wg, s);
+            if (rc > 0 && g0 > 0) { set_error("gemm_x3: launch refused after part of the group ran"); return -1; }
             if (rc != 0) return rc;
             continue;
         }
