@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMQG_ABI_VERSION 5
+#define MMQG_ABI_VERSION 6
 #define MMQG_MAX_LAYERS 8
 
 typedef void* mmqg_stream; /* hipStream_t */
@@ -162,6 +162,12 @@ int mmqg_projection_fwd(int rows, int V, int H, const float* h, int ldh, const f
 int mmqg_ce_fwd_bwd_stats(const float* logits, int ld, const int64_t* target, const float* row_weight,
                           int rows, int V, const float* stats, int stats_tiles, float* loss_rows,
                           int64_t* argmax, float* dlogits, int ld_d, mmqg_stream stream);
+/* Weight and bias gradient of a Linear layer y = x W^T + b (autograd of decoder.py:106, the vocabulary projection):
+ * dW[out][in] += dY^T X over `rows` rows, dbias[out] += column sums of dY (nullable).  dY is [rows][out] (ld_dy),
+ * X is [rows][in] (ldx).  The column sums ride in the product's operand staging pass when the split-bf16 kernel
+ * takes the shape; otherwise they are a sweep of their own. */
+int mmqg_linear_wgrad(int out_features, int in_features, int rows, const float* dY, int ld_dy,
+                      const float* X, int ldx, float* dW, int lddw, float* dbias, mmqg_stream stream);
 int mmqg_colsum_add(const float* X, int ld, int M, int N, float* out, mmqg_stream stream);
 int mmqg_reduce_sum(const float* x, int n, float* out, mmqg_stream stream);
 

@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmqg_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LAYERS = 8
 
 K_MAJOR, MN_MAJOR = 0, 1
@@ -161,6 +161,7 @@ SIGNATURES = {
     "mmqg_projection_stats_ws_bytes": [c_i, c_i],
     "mmqg_projection_last_kernel": [],
     "mmqg_projection_fwd": [c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_f, c_i64, C.POINTER(C.c_int32), c_f],
+    "mmqg_linear_wgrad": [c_i, c_i, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_f],
     "mmqg_colsum_add": [c_f, c_i, c_i, c_i, c_f, c_f],
     "mmqg_reduce_sum": [c_f, c_i, c_f, c_f],
     "mmqg_adam_step": [c_f, c_f, c_f, c_f, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, c_f, c_fl, c_f],

@@ -120,6 +120,15 @@ int mmqg_ce_fwd_bwd_stats(const float* logits, int ld, const int64_t* target, co
     return ce_fwd_bwd(logits, ld, target, row_weight, rows, V, loss_rows, argmax, dlogits, ld_d, S(stream), stats,
                       stats_tiles);
 }
+int mmqg_linear_wgrad(int out_features, int in_features, int rows, const float* dY, int ld_dy, const float* X, int ldx,
+                      float* dW, int lddw, float* dbias, mmqg_stream stream) {
+    if (out_features <= 0 || in_features <= 0 || rows <= 0) return 0;
+    MMQG_REQUIRE(dY && X && dW, "linear_wgrad: null operand");
+    MMQG_REQUIRE(ld_dy >= out_features && ldx >= in_features && lddw >= in_features, "linear_wgrad: leading dimension too small");
+    const GemmProblem q{out_features, in_features, rows, dY, ld_dy, X, ldx, dW, lddw, 1};
+    float* cs[1] = {dbias};
+    return gemm_f32_wgrad_group(&q, dbias ? cs : nullptr, nullptr, 1, S(stream));
+}
 static int g_projection_kernel = 0;
 int mmqg_projection_last_kernel(void) { return g_projection_kernel; }
 int64_t mmqg_projection_stats_ws_bytes(int rows, int V) { return rows > 0 && V > 0 ? gemm_nt_stats_bytes(rows, V) : 0; }

@@ -447,6 +447,39 @@ int gemm_f32(int a_layout, int b_layout, int M, int N, int K, const float* A, in
     return launch<128, 128, 16>(a, a_layout, b_layout, s);
 }
 
+int gemm_f32_wgrad_group(const GemmProblem* probs, float* const* colsum, float* const* colsum2, int n, hipStream_t s) {
+    MMQG_REQUIRE(n >= 0 && (n == 0 || probs), "gemm_f32_wgrad_group: bad arguments");
+    constexpr int cap = 2 * MMQG_MAX_LAYERS + 4;
+    GemmProblem big[cap], rest[cap];
+    float* cs1[cap]; float* cs2[cap];
+    int nb = 0, nr = 0;
+    bool fused = n <= cap;
+    for (int i = 0; i < n && fused; ++i) {
+        const GemmProblem& q = probs[i];
+        if (q.A && q.B && q.C && gemm_x3_wants(q.M, q.N, q.K)) {
+            big[nb] = q; cs1[nb] = colsum ? colsum[i] : nullptr; cs2[nb] = colsum2 ? colsum2[i] : nullptr; ++nb;
+        } else {
+            rest[nr++] = q;
+        }
+    }
+    if (fused && nb > 0) {
+        const int rc = gemm_x3_grouped(MMQG_MN_MAJOR, MMQG_MN_MAJOR, big, nullptr, nullptr, nb, s, cs1, cs2);
+        if (rc < 0) return rc;
+        fused = rc == 0;
+    } else {
+        fused = false;
+    }
+    // column sums the fused launch did not take: one sweep over A each (A_i is [K][M], lda)
+    for (int i = 0; i < n; ++i) {
+        if (!colsum || !colsum[i]) continue;
+        const GemmProblem& q = probs[i];
+        const bool taken = fused && q.A && q.B && q.C && gemm_x3_wants(q.M, q.N, q.K);
+        if (!taken) MMQG_TRY(colsum_add2(q.A, q.lda, q.K, q.M, colsum[i], colsum2 ? colsum2[i] : nullptr, s));
+    }
+    if (fused) return nr > 0 ? gemm_f32_grouped(MMQG_MN_MAJOR, MMQG_MN_MAJOR, rest, nr, s) : 0;
+    return gemm_f32_grouped(MMQG_MN_MAJOR, MMQG_MN_MAJOR, probs, n, s);
+}
+
 int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n, hipStream_t s) {
     MMQG_REQUIRE(n >= 0 && (n == 0 || probs), "gemm_f32_grouped: bad arguments");
     static const int no_group = env_int("MMQG_GEMM_NO_GROUP", 0);

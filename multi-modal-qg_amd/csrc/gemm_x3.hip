@@ -59,6 +59,8 @@ struct X3Problem {
     int tiles_n;
     int wg0;                         // first workgroup of this problem in the launch
     float4* stats;                   // ping-pong kernel, STATS variant: [M][tiles_n] {max, sum exp(x - max), argmax bits, 0}
+    float* colsum; float* colsum2;   // ping-pong kernel, m-major A: out[m] += sum over k of A[k][m] (bias gradients: the
+                                     // column sums of the gate gradients ride in the weight-gradient product's staging pass)
 };
 
 struct X3Batch {
@@ -417,23 +419,38 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
             if (AK) { fetch_k(p.A, off_a, lim_a, kb, x0); fetch_k(p.A, off_b, lim_b, kb, x1); }
             else { fetch_m(p.A, p.lda, off_a, kb, x0); fetch_m(p.A, p.lda, off_b, kb + 16, x1); }
         };
+        // m-major A with a column-sum request (first column tile only): this thread owns row m0 + t for both k halves,
+        // so the sum over k of its raw values is the row's sum — taken on the staged registers, after the tail mask
+        const bool want_sum = !AK && p.colsum != nullptr && tn == 0;
+        float rsum = 0.f;
+        auto tally = [&](int c, const float (&x0)[16], const float (&x1)[16]) {
+            if (!want_sum || c >= n_ch) return;                         // uniform
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rsum += x0[j] + x1[j];
+        };
         float xe0[16], xe1[16], xo0[16], xo1[16];
         if (n_ch > 0) {
             fetch(0, xe0, xe1); fetch(1, xo0, xo1);
-            put1(0, da0[0], da1[0], half_a, xe0); put1(0, db0[0], db1[0], half_b, xe1);
+            put1(0, da0[0], da1[0], half_a, xe0); put1(0, db0[0], db1[0], half_b, xe1); tally(0, xe0, xe1);
             fetch(2, xe0, xe1);
         }
         __syncthreads();
         for (int k = 0; k < n_ch; k += 2) {
-            put1(k + 1, da0[1], da1[1], half_a, xo0); put1(k + 1, db0[1], db1[1], half_b, xo1); fetch(k + 3, xo0, xo1);
+            put1(k + 1, da0[1], da1[1], half_a, xo0); put1(k + 1, db0[1], db1[1], half_b, xo1); tally(k + 1, xo0, xo1);
+            fetch(k + 3, xo0, xo1);
             __syncthreads();
             products(0);
             __syncthreads();
             if (k + 1 >= n_ch) break;
-            put1(k + 2, da0[0], da1[0], half_a, xe0); put1(k + 2, db0[0], db1[0], half_b, xe1); fetch(k + 4, xe0, xe1);
+            put1(k + 2, da0[0], da1[0], half_a, xe0); put1(k + 2, db0[0], db1[0], half_b, xe1); tally(k + 2, xe0, xe1);
+            fetch(k + 4, xe0, xe1);
             __syncthreads();
             products(1);
             __syncthreads();
+        }
+        if (want_sum && m0 + t < p.M) {
+            atomicAdd(p.colsum + m0 + t, rsum);
+            if (p.colsum2) atomicAdd(p.colsum2 + m0 + t, rsum);
         }
     }
 
@@ -587,11 +604,12 @@ int gemm_x3_projection(int M, int N, int K, const float* A, int lda, const float
 
 // 0 = launched; 1 = not taken (caller falls back); < 0 error.  All problems share one layout pair.
 int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const float* const* bias, const float* const* bias2,
-                    int n, hipStream_t s) {
+                    int n, hipStream_t s, float* const* colsum, float* const* colsum2) {
     if (n <= 0) return 0;
     if (!gemm_x3_enabled() || x3_cus() < 64) return 1;
     if (a_layout == MMQG_MN_MAJOR && b_layout == MMQG_K_MAJOR) return 1;       // no caller; not instantiated
     static const bool pp = [] { const char* e = getenv("MMQG_X3_PP"); return !e || atoi(e) != 0; }();
+    if (colsum && !(pp && a_layout == MMQG_MN_MAJOR)) return 1;                // fused column sums: ping-pong kernel, m-major A
     const int tile_m = pp ? kPM : kTile, tile_n = pp ? kPN : kTile;
     // every problem is checked BEFORE anything is launched: "not taken" must leave all outputs untouched
     for (int i = 0; i < n; ++i) {
@@ -622,6 +640,7 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
             p.M = q.M; p.N = q.N; p.K = q.K;
             p.A = q.A; p.lda = q.lda; p.B = q.B; p.ldb = q.ldb; p.C = q.C; p.ldc = q.ldc;
             p.bias = bias ? bias[g0 + i] : nullptr; p.bias2 = bias2 ? bias2[g0 + i] : nullptr;
+            p.colsum = colsum ? colsum[g0 + i] : nullptr; p.colsum2 = (colsum && colsum2) ? colsum2[g0 + i] : nullptr;
             p.beta = q.beta ? 1 : 0;
             p.tiles_n = ceil_div(q.N, tile_n);
             const int tiles = ceil_div(q.M, tile_m) * p.tiles_n;

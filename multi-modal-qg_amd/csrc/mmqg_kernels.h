@@ -29,8 +29,13 @@ int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n
 bool gemm_x3_wants(int M, int N, int K);
 int gemm_x3_projection(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias, float* C,
                        int ldc, float* stats, int64_t stats_bytes, int* stats_tiles, hipStream_t s);
+// colsum / colsum2 (nullable arrays, nullable entries; m-major A only): out[m] += sum over k of A[k][m]
 int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const float* const* bias, const float* const* bias2,
-                    int n, hipStream_t s);
+                    int n, hipStream_t s, float* const* colsum = nullptr, float* const* colsum2 = nullptr);
+// weight-gradient group C_i += A_i^T B_i (both m/n-major) that also adds the column sums of A_i (the bias gradients) into
+// colsum_i / colsum2_i where those are given: fused into the split-bf16 product's staging pass when that kernel takes
+// the problem, a separate sweep otherwise
+int gemm_f32_wgrad_group(const GemmProblem* probs, float* const* colsum, float* const* colsum2, int n, hipStream_t s);
 
 // ---- lstm_cell.hip --------------------------------------------------------------------
 struct CellFwd {

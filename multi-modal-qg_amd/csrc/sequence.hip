@@ -305,6 +305,8 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
         // recurrence-free products over all T*B rows: layer-0 input gradient, then every weight gradient of the
         // stack as ONE grouped launch (dW += dGates^T X), bias gradients (b_ih and b_hh get the same sums)
         GemmProblem wg[2 * MMQG_MAX_LAYERS];
+        float* cs1[2 * MMQG_MAX_LAYERS] = {};
+        float* cs2[2 * MMQG_MAX_LAYERS] = {};
         int nw = 0;
         for (int l = L - 1; l >= 0; --l) {
             const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
@@ -316,11 +318,16 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
                 MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, T * B, in, 4 * H, dg_l, 4 * H, d.w_ih[0], in, nullptr, 0,
                                   nullptr, 0, 0, nullptr, nullptr, 0, g.dx, g.lddx, -1, s));
             if (g.dw_ih[l]) wg[nw++] = GemmProblem{4 * H, in, T * B, dg_l, 4 * H, X, ldx, g.dw_ih[l], in, 1};
+            const int before = nw;
             if (g.dw_hh[l]) wg[nw++] = GemmProblem{4 * H, H, T * B, dg_l, 4 * H, hs_l, H, g.dw_hh[l], H, 1};
-            if (g.db_ih[l]) MMQG_TRY(colsum_add2(dg_l, 4 * H, T * B, 4 * H, g.db_ih[l], g.db_hh[l], s));
-            else if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, T * B, 4 * H, g.db_hh[l], s));
+            // bias gradients = column sums of the gate gradients: they ride in one of the layer's weight-gradient
+            // products (its staging pass reads every dG element anyway), or get a sweep of their own
+            float* b1 = g.db_ih[l] ? g.db_ih[l] : g.db_hh[l];
+            float* b2 = g.db_ih[l] ? g.db_hh[l] : nullptr;
+            if (b1 && nw > before) { cs1[nw - 1] = b1; cs2[nw - 1] = b2; }
+            else if (b1) MMQG_TRY(colsum_add2(dg_l, 4 * H, T * B, 4 * H, b1, b2, s));
         }
-        MMQG_TRY(gemm_f32_grouped(MMQG_MN_MAJOR, MMQG_MN_MAJOR, wg, nw, s));
+        MMQG_TRY(gemm_f32_wgrad_group(wg, cs1, cs2, nw, s));
     }
     return 0;
 }
@@ -578,6 +585,8 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
     }
     // every weight gradient of the decoder (dW += dX^T Y over all T*B rows) as grouped launches
     GemmProblem wg[2 * MMQG_MAX_LAYERS + 3];
+    float* cs1[2 * MMQG_MAX_LAYERS + 3] = {};
+    float* cs2[2 * MMQG_MAX_LAYERS + 3] = {};
     int nw = 0;
     if (g.dw_attn) {
         wg[nw++] = GemmProblem{S, E, R, g.dscores, ldD, d.xemb, E, g.dw_attn, Q, 1};
@@ -596,11 +605,14 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
                 wg[nw++] = GemmProblem{4 * H, H, R, dg_l, 4 * H, X, H, g.dw_ih[l], H, 1};
             }
         }
+        const int before = nw;
         if (g.dw_hh[l]) wg[nw++] = GemmProblem{4 * H, H, R, dg_l, 4 * H, hs_l, H, g.dw_hh[l], H, 1};
-        if (g.db_ih[l]) MMQG_TRY(colsum_add2(dg_l, 4 * H, R, 4 * H, g.db_ih[l], g.db_hh[l], s));
-        else if (g.db_hh[l]) MMQG_TRY(colsum_add(dg_l, 4 * H, R, 4 * H, g.db_hh[l], s));
+        float* b1 = g.db_ih[l] ? g.db_ih[l] : g.db_hh[l];
+        float* b2 = g.db_ih[l] ? g.db_hh[l] : nullptr;
+        if (b1 && nw > before) { cs1[nw - 1] = b1; cs2[nw - 1] = b2; }        // bias gradients ride in the dW_hh product
+        else if (b1) MMQG_TRY(colsum_add2(dg_l, 4 * H, R, 4 * H, b1, b2, s));
     }
-    MMQG_TRY(gemm_f32_grouped(MMQG_MN_MAJOR, MMQG_MN_MAJOR, wg, nw, s));
+    MMQG_TRY(gemm_f32_wgrad_group(wg, cs1, cs2, nw, s));
     return 0;
 }
 

@@ -145,6 +145,15 @@ def ce_fwd_bwd(logits: torch.Tensor, target: Optional[torch.Tensor], row_weight:
     return loss_rows, argmax, dlogits
 
 
+def linear_wgrad(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor]) -> None:
+    """dW += dY^T X, dbias += dY.sum(0) (the weight / bias gradient of y = x W^T + b, decoder.py:106); rows contiguous."""
+    require_device(dY, X, dW, dbias)
+    rows, out_f = dY.shape
+    in_f = X.shape[1]
+    check(_lib.load().mmqg_linear_wgrad(out_f, in_f, rows, dY.data_ptr(), dY.stride(0), X.data_ptr(), X.stride(0),
+                                        dW.data_ptr(), dW.stride(0), ptr(dbias), _stream()), "linear_wgrad")
+
+
 def colsum_add(X: torch.Tensor, out: torch.Tensor) -> None:
     M, N = X.shape
     check(_lib.load().mmqg_colsum_add(X.data_ptr(), X.stride(0), M, N, out.data_ptr(), _stream()), "colsum_add")

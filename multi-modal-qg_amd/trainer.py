@@ -584,8 +584,8 @@ class BatchedTrainer:
         # vocabulary projection backward (logits now holds dlogits): weight gradient on the side stream
         def vocab_side():            # weight gradient of the projection; the loss scalar is off the chain too
             check(lib.mmqg_reduce_sum(w["loss_rows"].data_ptr(), R, w["loss"].data_ptr(), ops._stream()), "reduce_sum")
-            ops.gemm(MN_MAJOR, MN_MAJOR, V, H, R, logits, V, htop, H, out.weight.grad, H, beta=1)
-            ops.colsum_add(logits, out.bias.grad)
+            check(lib.mmqg_linear_wgrad(V, H, R, logits.data_ptr(), V, htop.data_ptr(), H, out.weight.grad.data_ptr(), H,
+                                        out.bias.grad.data_ptr(), ops._stream()), "linear_wgrad")
 
         def vocab_chain():
             ops.gemm(K_MAJOR, MN_MAJOR, R, H, V, logits, V, out.weight, H, w["dhtop"], H)

@@ -429,6 +429,25 @@ def test_projection_with_loss_statistics_equals_the_three_sweep_loss(mm, rows, V
     close(d1, d3, tol=2e-6, what="dlogits, one sweep against three")
 
 
+@pytest.mark.parametrize("rows,out_f,in_f", [(1280, 10000, 512), (1000, 2049, 520), (7, 50, 12), (600, 300, 96)])
+def test_linear_weight_and_bias_gradient_in_one_product(mm, rows, out_f, in_f):
+    """Autograd of decoder.py:106 (nn.Linear): dW += dY^T X and db += column sums of dY.  On large shapes the column
+    sums are taken from the registers of the product's staging pass (csrc/gemm_x3.hip), on small ones by a sweep."""
+    _lib, ops = mm
+    g = torch.Generator().manual_seed(rows + out_f)
+    dY = torch.randn(rows, out_f, generator=g) * 0.1
+    X = torch.randn(rows, in_f, generator=g)
+    dW0 = torch.randn(out_f, in_f, generator=g)
+    db0 = torch.randn(out_f, generator=g)
+    dW, db = dev(dW0), dev(db0)
+    ops.linear_wgrad(dev(dY), dev(X), dW, db)
+    close(dW, (dW0.double() + dY.double().t() @ X.double()).float(), tol=4e-6, what="dW")
+    close(db, (db0.double() + dY.double().sum(0)).float(), tol=4e-6, what="db")
+    dW2 = dev(dW0)
+    ops.linear_wgrad(dev(dY), dev(X), dW2, None)                     # no bias gradient asked for
+    close(dW2, dW, tol=1e-6, what="dW without db")
+
+
 def test_colsum_and_reduce_sum(mm):
     _lib, ops = mm
     g = torch.Generator().manual_seed(1)
@@ -481,7 +500,10 @@ def test_adam_matches_oracle_over_steps(mm):
                                           # shapes the persistent forward time loop takes (csrc/persist.hip): partial
                                           # row blocks, 1..4 row blocks per unit, 1..3 layers, dropout on and off
                                           (6, 5, 3, 128, 40, 0.25), (5, 20, 2, 128, 64, 0.0), (4, 64, 1, 256, 32, 0.0),
-                                          (9, 33, 3, 192, 24, 0.3), (3, 48, 2, 512, 16, 0.2)])
+                                          (9, 33, 3, 192, 24, 0.3), (3, 48, 2, 512, 16, 0.2),
+                                          # T*B = 1536 rows: the weight gradients go through the split-bf16 GEMM group, the
+                                          # bias gradients ride in its staging pass (csrc/gemm_x3.hip); T*B not a multiple of 32
+                                          (24, 64, 2, 256, 64, 0.2), (17, 45, 2, 256, 48, 0.0)])
 def test_lstm_sequence_executor_forward_backward(mm, T, B, L, H, In, p):
     """mmqg_lstm_seq_fwd/bwd (autograd wrapper LSTMSeqFn) vs the oracle's stacked cell loop, with
     a given initial state and the executor's own dropout masks replayed into the oracle."""

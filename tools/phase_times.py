@@ -50,8 +50,8 @@ def vocab_bwd():
     out = tr.dec.out_layer
     htop = ws["hs_d"][L - 1, 1:].reshape(R, H)
     ops.gemm(0, 1, R, H, V, ws["logits"], V, out.weight, H, ws["dhtop"], H)
-    ops.gemm(1, 1, V, H, R, ws["logits"], V, htop, H, out.weight.grad, H, beta=1)
-    ops.colsum_add(ws["logits"], out.bias.grad)
+    check(lib.mmqg_linear_wgrad(V, H, R, ws["logits"].data_ptr(), V, htop.data_ptr(), H, out.weight.grad.data_ptr(), H,
+                                out.bias.grad.data_ptr(), s()))
 
 
 phases = [
