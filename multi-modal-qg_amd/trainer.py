@@ -87,6 +87,7 @@ class BatchedTrainer:
         self.drop_dec = float(dec.dropout_p)
         self.training = True
         self.grad_hook: Optional[Callable[["BatchedTrainer", str], None]] = None
+        self._early_adam = False          # set while the single-GPU graph step is warmed up / captured
         self._flatten_parameters()
         self._allocate()
         self._describe()
@@ -547,6 +548,11 @@ class BatchedTrainer:
                     check(lib.mmqg_frame_cnn_bwd(C.byref(self.d_cnn), C.byref(self.g_cnn), s2), "frame_cnn_bwd")
                 if self.distributed and not torch.cuda.is_current_stream_capturing():
                     self.reducer.reduce("vid")          # frame encoder gradients are final too
+            if which == "both" and self._early_adam:
+                # single GPU, captured step: the decoder's and the frame encoder's gradients are final here, and nothing
+                # later in the step reads their parameters — their Adam (HBM-bound) runs on this branch beside the text
+                # encoder's backward (latency-bound) instead of after it
+                self._adam("early")
 
         def enc_chain():             # text encoder backward: the rest of the dependent chain
             self.g_text.phase = 1
@@ -629,6 +635,11 @@ class BatchedTrainer:
             self._tr_jobs = arr
         check(_lib.load().mmqg_transpose_f32_batch(self._tr_jobs, len(self._tr_jobs), ops._stream()), "transpose_f32_batch")
 
+    def _adam_split(self) -> int:
+        """First element of the 'rest' bucket (0: the flat layout has no dec | vid | rest split)."""
+        bk = self.reducer.buckets
+        return bk["rest"][0] if "rest" in bk and "vid" in bk else 0
+
     def _adam(self, part: str = "all"):
         """Adam over the flat buffer.  part 'all': everything (+ the embedding's second optimizer), both counters
         advance.  Data-parallel graph step: 'early' = decoder + frame-encoder segments as soon as their buckets are
@@ -636,7 +647,7 @@ class BatchedTrainer:
         lib, s = _lib.load(), ops._stream()
         b1, b2 = self.betas
         scale = 1.0 / self.world
-        split = self.reducer.buckets["rest"][0] if "rest" in self.reducer.buckets and "vid" in self.reducer.buckets else 0
+        split = self._adam_split()
         if part in ("all", "early"):
             check(lib.mmqg_counter_add(self.adam_dev.data_ptr(), 1, s), "counter_add")
         lo, hi = {"all": (0, self.n_params), "early": (0, split), "late": (split, self.n_params)}[part]
@@ -707,12 +718,20 @@ class BatchedTrainer:
             bn_stats = [b for i in (1, 2, 3, 4) for b in (getattr(self.video, f"bn{i}").running_mean,
                                                           getattr(self.video, f"bn{i}").running_var)] if self._cnn_on else []
             saved = [b.clone() for b in bn_stats]
+            # single GPU: Adam of the decoder + frame-encoder segments rides inside the step graph (see enc_side)
+            split_early = (not dp) and self.grad_hook is None and self._adam_split() > 0 \
+                and os.environ.get("MMQG_NO_EARLY_ADAM", "0") != "1"
+            self._early_adam = split_early
+            adam_state = [t.clone() for t in (self.flat_p, self.flat_m, self.flat_v, self.emb_m2, self.emb_v2,
+                                              self.counters)] if split_early else []
             with torch.cuda.stream(warm):      # warm-up outside capture (lazy code-object loads)
                 for part in parts:
                     self._graph_body(part)
             torch.cuda.current_stream().wait_stream(warm)
             for b, v in zip(bn_stats, saved):  # the warm-up pass must not count as a training step
                 b.copy_(v)
+            for t, v in zip((self.flat_p, self.flat_m, self.flat_v, self.emb_m2, self.emb_v2, self.counters), adam_state):
+                t.copy_(v)                      # ... nor update parameters (its early Adam ran)
             torch.cuda.synchronize()
             if dp:
                 self.reducer.discard()          # the warm-up pass ran eagerly and may have queued reductions
@@ -725,7 +744,9 @@ class BatchedTrainer:
                 pool = g.pool()
                 self._graphs[part] = g
             self._graph = self._graphs[parts[0]]
-            for part in (("early", "late") if dp else ("all",)):
+            self._early_adam = False
+            self._graph_early_adam = split_early
+            for part in (("early", "late") if dp else (("late",) if split_early else ("all",))):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     self._adam(part)
@@ -734,7 +755,7 @@ class BatchedTrainer:
         if not dp:
             G["all"].replay()
             self._count_bn_batches()
-            G["adam_all"].replay()
+            G["adam_late" if self._graph_early_adam else "adam_all"].replay()
             return self.ws["loss"]
         main = torch.cuda.current_stream()
         G["dec"].replay()

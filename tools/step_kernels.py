@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Every kernel of one steady-state step from a rocprofv3 kernel_trace.csv, in start order: start, queue, duration."""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+lo, hi = adam[-7] + 1, adam[-5]
+step = rows[lo:hi + 1]
+t0 = int(step[0]["Start_Timestamp"])
+for r in step:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-44:]
+    print(f"{(s - t0) / 1e3:8.1f} q{r['Queue_Id']:>2s} {(e - s) / 1e3:7.1f} {n} grid={r['Grid_Size']}")
