@@ -631,7 +631,7 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
             const GemmProblem& q = probs[g0 + i];
             tiles_total += (int64_t)ceil_div(q.M, tile_m) * ceil_div(q.N, tile_n);
         }
-        // k slices: fill the chip's workgroup slots, keep >= 8 chunks per slice
+        // k slices: fill the chip's workgroup slots once, keep >= 8 chunks per slice
         const int slots = (pp ? 1 : 2) * x3_cus();
         int wg = 0;
         for (int i = 0; i < ng; ++i) {
@@ -647,7 +647,11 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
             const int nch = ceil_div(q.K, kBK);
             int split = 1;
             if (tiles_total < slots) {
-                split = (int)std::min<int64_t>((slots + tiles_total - 1) / tiles_total, 16);
+                // as many slices as fit ONE round of workgroups (a partly filled second round costs a whole one), at most
+                // 8: every slice adds its 256 x 128 partial tile with f32 atomics (tools/x3_split.py: the 1280 x 512 x
+                // 10000 data gradient takes 127 us at 8 slices, 143 at 13, 205 at 4)
+                static const int max_split = [] { const char* e = getenv("MMQG_X3_MAX_SPLIT"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+                split = (int)std::min<int64_t>(std::max<int64_t>(slots / tiles_total, 1), max_split);
                 split = std::min(split, std::max(1, nch / 8));
             }
             p.split_k = split;

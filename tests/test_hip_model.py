@@ -740,3 +740,26 @@ def test_bench_self_launch_runs_a_rank_through_rccl(mm):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["world_size"] == 1 and "nccl" in d["config"]["collective_backend"]
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["roofline"]["achieved_beyond_mall"] > 0
+
+
+def test_fp32_matrix_core_kernels_give_the_same_training_step(mm):
+    """The large products run on the bf16 matrix cores with exactly split fp32 operands (csrc/gemm_x3.hip); with
+    MMQG_GEMM_X3=0 they run on the fp32 MFMA kernels.  Both are fp32 arithmetic: after the same five training steps
+    of config 2 (dropout live, same seeds) the two losses agree to 1e-5 relative — and the fallback family keeps
+    being exercised."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    losses = {}
+    for x3 in ("1", "0"):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env["MMQG_GEMM_X3"] = x3
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2",
+                            "--no-cpu-baseline", "--kernel-iters", "5"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        losses[x3] = d["final_loss"]
+        want = "gemm_x3pp" if x3 == "1" else "gemm_nt_tile"
+        assert want in d["roofline_mfma"]["kernel"], d["roofline_mfma"]["kernel"]
+    assert abs(losses["1"] - losses["0"]) <= 1e-5 * abs(losses["0"]), losses
