@@ -449,188 +449,6 @@ __global__ __launch_bounds__(256, 1) void cell_fwd_wide_kernel(SkinnyBatch batch
     }
 }
 
-// Wide backward layer-step (and the plain products that ride in its launches): 64 rows x 32 hidden units per 4-wave
-// workgroup, same operand path and register blocking as cell_fwd_wide_kernel.  At config 5 a backward layer-step is
-// dh[128 x 1024] over K = 8192 (two gate-gradient operands): 512 workgroups of one 16 x 16 tile pulled 512 MB through
-// the L2s (88 us); 64 workgroups of 64 x 32 pull 192 MB.
-constexpr int kWideCols = 32;
-
-__global__ __launch_bounds__(256, 1) void cell_bwd_wide_kernel(SkinnyBatch batch) {
-    __shared__ float part[4][kWideRows][33];      // the plain and the masked partial tiles take turns in it
-    const SkinnyK& a = batch.job[blockIdx.z];
-    const int m0 = blockIdx.y * kWideRows, n0 = blockIdx.x * kWideCols;
-    if (m0 >= a.M || n0 >= a.N) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, kq = lane >> 4;
-    const int lr = lane >> 2, ls = lane & 3;
-    const int src_lane = 4 * c + kq;
-    int ra[4], nb[2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ra[r] = min(m0 + 16 * r + lr, a.M - 1);
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) nb[cc] = min(n0 + 16 * cc + lr, a.N - 1);
-    const int per = (a.chunks + 3) / 4;
-    const int q0 = wave * per, q1 = min(a.chunks, q0 + per);
-    f32x4 acc_p[4][2], acc_m[4][2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) { acc_p[r][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_m[r][cc] = acc_p[r][cc]; }
-#pragma unroll
-    for (int pi = 0; pi < 3; ++pi) {
-        const int pbeg = pi == 0 ? 0 : (pi == 1 ? a.cs1 : a.cs2);
-        const int pend = pi == 0 ? min(a.cs1, a.chunks) : (pi == 1 ? min(a.cs2, a.chunks) : a.chunks);
-        const int lo = max(q0, pbeg), hi = min(q1, pend);
-        if (lo >= hi) continue;
-        const float* __restrict__ Ap[4];
-        const float* __restrict__ Bp[2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ap[r] = a.p[pi].A + (int64_t)ra[r] * a.p[pi].lda;
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) Bp[cc] = a.p[pi].B + (int64_t)nb[cc] * a.p[pi].ldb;
-        const int K = a.p[pi].K;
-        const bool masked = a.p[pi].masked && !a.plain;
-        constexpr int U = 4;
-        for (int q = lo; q < hi; q += U) {
-            float4 av[4][U], bv[2][U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = (q + u - pbeg) * 16 + 4 * ls;
-                const bool in = q + u < hi && k < K;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) av[r][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) bv[cc][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) av[r][u] = *reinterpret_cast<const float4*>(Ap[r] + k);
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) bv[cc][u] = *reinterpret_cast<const float4*>(Bp[cc] + k);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    av[r][u].x = __shfl(av[r][u].x, src_lane, 64); av[r][u].y = __shfl(av[r][u].y, src_lane, 64);
-                    av[r][u].z = __shfl(av[r][u].z, src_lane, 64); av[r][u].w = __shfl(av[r][u].w, src_lane, 64);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    bv[cc][u].x = __shfl(bv[cc][u].x, src_lane, 64); bv[cc][u].y = __shfl(bv[cc][u].y, src_lane, 64);
-                    bv[cc][u].z = __shfl(bv[cc][u].z, src_lane, 64); bv[cc][u].w = __shfl(bv[cc][u].w, src_lane, 64);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (masked) {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int cc = 0; cc < 2; ++cc) {
-                            acc_m[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].x, bv[cc][u].x, acc_m[r][cc], 0, 0, 0);
-                            acc_m[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].y, bv[cc][u].y, acc_m[r][cc], 0, 0, 0);
-                            acc_m[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].z, bv[cc][u].z, acc_m[r][cc], 0, 0, 0);
-                            acc_m[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].w, bv[cc][u].w, acc_m[r][cc], 0, 0, 0);
-                        }
-            } else {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int cc = 0; cc < 2; ++cc) {
-                            acc_p[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].x, bv[cc][u].x, acc_p[r][cc], 0, 0, 0);
-                            acc_p[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].y, bv[cc][u].y, acc_p[r][cc], 0, 0, 0);
-                            acc_p[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].z, bv[cc][u].z, acc_p[r][cc], 0, 0, 0);
-                            acc_p[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].w, bv[cc][u].w, acc_p[r][cc], 0, 0, 0);
-                        }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // k-slice sums of this thread's 8 outputs: plain products first, then (same LDS) the masked ones
-    float s8[8], sm8[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) part[wave][16 * r + 4 * kq + e][16 * cc + c] = acc_p[r][cc][e];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int pp = threadIdx.x + 256 * it;
-        s8[it] = part[0][pp >> 5][pp & 31] + part[1][pp >> 5][pp & 31] + part[2][pp >> 5][pp & 31] + part[3][pp >> 5][pp & 31];
-        sm8[it] = 0.f;
-    }
-    const bool any_masked = !a.plain && (a.p[0].masked || a.p[1].masked || a.p[2].masked);
-    if (any_masked) {                                   // uniform
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) part[wave][16 * r + 4 * kq + e][16 * cc + c] = acc_m[r][cc][e];
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int pp = threadIdx.x + 256 * it;
-            sm8[it] = part[0][pp >> 5][pp & 31] + part[1][pp >> 5][pp & 31] + part[2][pp >> 5][pp & 31] + part[3][pp >> 5][pp & 31];
-        }
-    }
-    const int H = a.H;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int pp = threadIdx.x + 256 * it;
-        const int row = pp >> 5, col = pp & 31;
-        const int b = m0 + row, j = n0 + col;
-        if (b >= a.M || j >= a.N) continue;
-        const float s = s8[it], sm = sm8[it];
-        if (a.plain) {
-            float* dst = a.C + (int64_t)b * a.ldc + j;
-            float v = s + (a.bias ? a.bias[j] : 0.f);
-            if (a.beta) v += *dst;
-            *dst = v;
-            continue;
-        }
-        const int64_t e = (int64_t)b * H + j;
-        float mask = 1.f;
-        bool have_mask = false;
-        float dh = s + a.carry[e] + (a.pre ? a.pre[e] : 0.f);
-        if (a.p[1].masked || a.p[2].masked || a.p[0].masked) {
-            if (a.drop_p > 0.f) mask = dropout_scale(eff_seed(a.seed, a.seed_off), a.stream_id, (uint64_t)e, a.drop_p);
-            have_mask = true;
-            dh += sm * mask;
-        }
-        const bool active = a.lens ? (a.t < a.lens[b]) : true;
-        float* dg = a.dgates + (int64_t)b * 4 * H;
-        if (!active) {
-            dg[j] = 0.f; dg[H + j] = 0.f; dg[2 * H + j] = 0.f; dg[3 * H + j] = 0.f;
-            a.carry[e] = dh;
-            continue;
-        }
-        if (a.above) {
-            if (!have_mask && a.drop_p > 0.f) mask = dropout_scale(eff_seed(a.seed, a.seed_off), a.stream_id, (uint64_t)e, a.drop_p);
-            dh += a.above[(int64_t)b * a.above_stride_b + j] * mask;
-        }
-        if (a.extra) dh += a.extra[(int64_t)b * a.extra_stride_b + j];
-        const float* gr = a.gates_act + (int64_t)b * 4 * H;
-        const float gi = gr[j], gf = gr[H + j], gg = gr[2 * H + j], go = gr[3 * H + j];
-        const float tc = tanhf(a.c_new[e]);
-        const float dct = a.dc[e] + dh * go * (1.f - tc * tc);
-        dg[j] = dct * gg * gi * (1.f - gi);
-        dg[H + j] = dct * a.c_prev[e] * gf * (1.f - gf);
-        dg[2 * H + j] = dct * gi * (1.f - gg * gg);
-        dg[3 * H + j] = dh * tc * go * (1.f - go);
-        a.dc[e] = dct * gf;
-        a.carry[e] = 0.f;
-    }
-}
-
 // dst[c][r] = src[r][c]   (rows x cols -> cols x rows), 32x32 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int ld_src, int rows, int cols,
                                                         float* __restrict__ dst, int ld_dst) {
@@ -707,30 +525,9 @@ int launch_skinny_batch(const SkinnyBatch& b, int njobs, hipStream_t s, const ch
             return mmqg::check_launch(what);
         }
     }
-    if (MODE == MODE_BWD_CELL || MODE == MODE_PLAIN) {
-        // large batch / wide layer: 64 x 32 tiles (cell job and the plain products riding with it, or plain products alone)
-        static const bool no_wide = [] { const char* e = getenv("MMQG_NO_WIDE"); return e && atoi(e) != 0; }();
-        int64_t wide_wgs = 0;
-        int wx = 0, wy = 0;
-        bool ok = !no_wide;
-        for (int i = 0; i < njobs && ok; ++i) {
-            const SkinnyK& k = b.job[i];
-            ok = k.M > 64;
-            const int tx = mmqg::ceil_div(k.N, kWideCols), ty = mmqg::ceil_div(k.M, kWideRows);
-            wide_wgs += (int64_t)tx * ty;
-            wx = std::max(wx, tx); wy = std::max(wy, ty);
-        }
-        // (64 workgroups of 64 x 32 lose to 512 of 16 x 16 — per-CU fetch rate, not total bytes, sets the time: 26.3 vs
-        // 23.9 ms per config-5 step — so this path waits for a k split across workgroups: MMQG_WIDE_BWD=1 to measure)
-        static const bool wide_bwd = [] { const char* e = getenv("MMQG_WIDE_BWD"); return e && atoi(e) != 0; }();
-        if (ok && wide_bwd && wide_wgs >= 48) {
-            SkinnyBatch wb = b;
-            if (MODE == MODE_PLAIN)
-                for (int i = 0; i < njobs; ++i) wb.job[i].plain = 1;
-            hipLaunchKernelGGL(cell_bwd_wide_kernel, dim3(wx, wy, njobs), dim3(256), 0, s, wb);
-            return mmqg::check_launch(what);
-        }
-    }
+    // (the backward layer-step stays on 16 x 16 tiles at every size: 64 x 32 tiles measured slower both alone — 64
+    // workgroups, per-CU fetch rate sets the time: config 5 26.3 vs 23.9 ms — and with k slices across workgroups meeting
+    // through f32 atomics and a ticket counter: 31.7 / 38.4 / 46.5 ms at 3 / 5 / 8 slices)
     dim3 grid(tiles_n, tiles_m, njobs);
     // 8 k-slices per tile once a tile has >= 64 k-chunks, unless that would put more than ~4096 waves
     // in flight (three layer-steps in one launch): beyond that the extra waves only add fixed cost
