@@ -591,8 +591,10 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
     if (g.dw_attn) {
         wg[nw++] = GemmProblem{S, E, R, g.dscores, ldD, d.xemb, E, g.dw_attn, Q, 1};
         wg[nw++] = GemmProblem{S, H, R, g.dscores, ldD, htop_prev, H, g.dw_attn + E, Q, 1};
+        if (g.db_attn) cs1[nw - 1] = g.db_attn;          // the score bias gradient rides in this product's staging pass
+    } else if (g.db_attn) {
+        MMQG_TRY(colsum_add(g.dscores, ldD, R, S, g.db_attn, s));
     }
-    if (g.db_attn) MMQG_TRY(colsum_add(g.dscores, ldD, R, S, g.db_attn, s));
     for (int l = 0; l < L; ++l) {
         const float* dg_l = g.dgates + (int64_t)l * T * G;
         const float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
