@@ -527,7 +527,8 @@ int launch_skinny_batch(const SkinnyBatch& b, int njobs, hipStream_t s, const ch
     }
     // (the backward layer-step stays on 16 x 16 tiles at every size: 64 x 32 tiles measured slower both alone — 64
     // workgroups, per-CU fetch rate sets the time: config 5 26.3 vs 23.9 ms — and with k slices across workgroups meeting
-    // through f32 atomics and a ticket counter: 31.7 / 38.4 / 46.5 ms at 3 / 5 / 8 slices)
+    // through f32 atomics and a ticket counter: 31.7 / 38.4 / 46.5 ms at 3 / 5 / 8 slices; 32 x 16 tiles in 8-wave
+    // workgroups, two per CU: 24.6 vs 24.2 ms)
     dim3 grid(tiles_n, tiles_m, njobs);
     // 8 k-slices per tile once a tile has >= 64 k-chunks, unless that would put more than ~4096 waves
     // in flight (three layer-steps in one launch): beyond that the extra waves only add fixed cost
