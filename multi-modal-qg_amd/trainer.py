@@ -478,6 +478,10 @@ class BatchedTrainer:
                 self.d_cnn.training = int(training)
                 check(lib.mmqg_frame_cnn_fwd(C.byref(self.d_cnn), s), "frame_cnn_fwd")
             check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_vid), s), "lstm_seq_fwd(frames)")
+            if not hoists_first:
+                decoder_hoists(s)
+
+        def decoder_hoists(s):
             ops.embedding_fwd(emb, w["ids_d"], w["xemb_d"].view(-1, self.E))
             self.d_dec.phase = 1
             check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd(hoists)")
@@ -485,8 +489,16 @@ class BatchedTrainer:
             # its fused loops read the k-major copies
             self._refresh_transposes()
 
+        # The text encoder's persistent time loop owns every CU while it runs, so whatever the other branch still has
+        # queued at that point waits for its end and the decoder loop then waits for the branch.  The decoder's hoisted
+        # products and the weight transposes (independent of both encoders) therefore go IN FRONT of the time loop on
+        # this stream, beside the frame encoder's short chain on the other.
+        hoists_first = os.environ.get("MMQG_HOISTS_LAST", "0") != "1"
+
         def chain():
             s = ops._stream()
+            if hoists_first:
+                decoder_hoists(s)
             ops.embedding_fwd(emb, w["ids_c"], w["xemb_c"].view(-1, self.E))
             check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_text), s), "lstm_seq_fwd(text)")
 
