@@ -41,5 +41,10 @@ int main() {
     run("square 4096 (NT)", 0, 0, 4096, 4096, 4096, 5);
     run("square 4096 (TN)", 1, 1, 4096, 4096, 4096, 5);
     run("vocab fwd (NT)", 0, 0, 1280, 10000, 512, 20);
+    run("vocab dgrad (NN)", 0, 1, 1280, 512, 10000, 20);
+    run("vocab wgrad (TN)", 1, 1, 10000, 512, 1280, 20);
+    run("config5 vocab fwd (NT)", 0, 0, 2560, 50000, 1024, 3);
+    run("config5 vocab dgrad (NN)", 0, 1, 2560, 1024, 50000, 3);
+    run("config5 vocab wgrad (TN)", 1, 1, 50000, 1024, 2560, 3);
     return 0;
 }
