@@ -45,11 +45,13 @@ static void report(const char* name, const std::vector<unsigned long long>& tr, 
            name, us_per_launch, mean[0], mx[0], mean[1], mx[1], mean[2], mx[2], mean[3], mx[3], mean[4] * nwg / std::max(have4, 1), mx[4]);
 }
 
-int main() {
+int main(int argc, char** argv) {
     CK(hipSetDevice(0));
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int B = 64, H = 512, L = 3, chain = 60;
+    const int B = argc > 1 ? atoi(argv[1]) : 64, H = argc > 2 ? atoi(argv[2]) : 512, chain = 60;
+    constexpr int L = 3;
+    printf("B = %d, H = %d\n", B, H);
     float* W_ih[L]; float* W_hh[L]; float* WT_ih[L]; float* WT_hh[L]; float* b1[L]; float* b2[L];
     for (int l = 0; l < L; ++l) {
         W_ih[l] = dalloc((size_t)4 * H * H, 0.02f); W_hh[l] = dalloc((size_t)4 * H * H, 0.02f);
@@ -64,7 +66,7 @@ int main() {
     float* dh = dalloc((size_t)L * B * H, 0.01f);
     float* dc = dalloc((size_t)L * B * H, 0.01f);
     const size_t BH = (size_t)B * H;
-    unsigned long long* trace; const int max_wg = 4096;
+    unsigned long long* trace; const int max_wg = 8192;
     CK(hipMalloc(&trace, (size_t)max_wg * 8 * 8));
     unsigned long long* null_trace = nullptr;
 
@@ -94,9 +96,10 @@ int main() {
     };
 
     struct Case { const char* name; int njobs; bool bwd; int nwg; int layer; };
-    const Case cases[] = {{"FWD_CELL 1 job (K=2x512)", 1, false, 128 * 4, 1}, {"FWD_CELL 3 jobs", 3, false, 128 * 4 * 3, 0},
-                          {"BWD_CELL 1 job (K=2x2048)", 1, true, 32 * 4, 1}, {"BWD_CELL 1 job (K=1x2048)", 1, true, 32 * 4, 2},
-                          {"BWD_CELL 3 jobs", 3, true, 32 * 4 * 3, 0}};
+    const int ft = (H / 4) * ((B + 15) / 16), bt = (H / 16) * ((B + 15) / 16);
+    const Case cases[] = {{"FWD_CELL 1 job (K=2xH)", 1, false, ft, 1}, {"FWD_CELL 3 jobs", 3, false, ft * 3, 0},
+                          {"BWD_CELL 1 job (K=2x4H)", 1, true, bt, 1}, {"BWD_CELL 1 job (K=1x4H)", 1, true, bt, 2},
+                          {"BWD_CELL 3 jobs", 3, true, bt * 3, 0}};
     for (const Case& cs_ : cases) {
         auto enqueue = [&](int t) {
             if (!cs_.bwd) {
