@@ -295,6 +295,13 @@ def main(argv=None):
     if self_launch_needed(a.gpus, os.environ):
         sys.exit(self_launch(a, argv))
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner on
+    # rank 0's stdout when the first communicator comes up), so everything before the result goes to stderr: file
+    # descriptor 1 points at stderr until the line is printed.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import mmqg_amd  # noqa: F401
     from mmqg_amd.synthetic import WORKLOADS, build_models, synthetic_batch
     from mmqg_amd.trainer import BatchedTrainer
@@ -367,6 +374,9 @@ def main(argv=None):
     if use_pg:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(result_fd, 1)
+    os.close(result_fd)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

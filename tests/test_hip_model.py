@@ -737,6 +737,7 @@ def test_bench_self_launch_runs_a_rank_through_rccl(mm):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, "stdout must hold the JSON line only (RCCL's banner goes to stderr)"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["world_size"] == 1 and "nccl" in d["config"]["collective_backend"]
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["roofline"]["achieved_beyond_mall"] > 0
