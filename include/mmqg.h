@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMQG_ABI_VERSION 6
+#define MMQG_ABI_VERSION 7
 #define MMQG_MAX_LAYERS 8
 
 typedef void* mmqg_stream; /* hipStream_t */
@@ -213,15 +213,19 @@ typedef struct {
     float* hdrop;                                   /* [L-1][T][B][H], NULL if no dropout */
     float* y; int64_t y_stride_t; int64_t y_stride_b; /* optional top-layer outputs (0 past lens) */
     float* persist_ws; int64_t persist_ws_bytes;    /* optional workspace (16-byte aligned, size from
-                                                       mmqg_lstm_seq_persist_ws_bytes): with it, and a shape the
-                                                       persistent kernel takes, the whole forward time loop is ONE
-                                                       launch whose workgroups keep the recurrent weights in LDS and
-                                                       meet at a device-wide barrier per wavefront diagonal.  The
-                                                       caller must not have TWO such launches in flight on one device
-                                                       (two streams, two processes): each could end up half resident
-                                                       and wait for workgroups the other one keeps off the CUs; the
-                                                       barrier's spins are bounded (seconds) and then poison hs with
-                                                       NaN instead of hanging */
+                                                       mmqg_lstm_seq_persist_ws_bytes, ZERO-FILLED ONCE by the caller):
+                                                       with it, and a shape the persistent kernels take, a whole time
+                                                       loop (forward; backward too) is ONE launch whose workgroups keep
+                                                       the recurrent weights in LDS and meet at device-wide barriers.
+                                                       Two such launches must not be in flight on one device at once
+                                                       (each could end up half resident and wait for workgroups the
+                                                       other keeps off the CUs): the library grants a request only on
+                                                       the stream of the previous persistent launch or once that one
+                                                       has completed, and to one stream per capture; a declined request
+                                                       takes the launch-per-diagonal path (same results).  What the
+                                                       host cannot see (another process on the device, two graphs
+                                                       replayed side by side) ends at a bounded spin: see
+                                                       mmqg_persist_failures() */
 } mmqg_lstm_seq;
 
 typedef struct {
@@ -239,19 +243,48 @@ typedef struct {
                                                        bias gradients + dx only (after a phase-1 call).  Lets a
                                                        caller run the large, recurrence-free GEMMs of phase 2 on
                                                        a second stream beside another sequence's time loop. */
+    float* persist_ws; int64_t persist_ws_bytes;    /* optional workspace of the persistent BACKWARD time loop (size
+                                                       from mmqg_lstm_seq_bwd_persist_ws_bytes, 16-byte aligned,
+                                                       zero-filled once by the caller): with it, and a shape that
+                                                       kernel takes, all T + L - 1 anti-diagonals of the backward
+                                                       wavefront are ONE launch (the recurrent weights cut along K
+                                                       and kept in LDS, partial products meeting through an exchange
+                                                       buffer behind a device-wide barrier).  Same residency rule and
+                                                       failure reporting as mmqg_lstm_seq.persist_ws */
 } mmqg_lstm_seq_grad;
 
 int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream);
 /* bytes of persist_ws the persistent forward needs for this shape; 0 = shape not taken (B > 64, H < 128 or not a
  * multiple of 16, ...): the forward then runs one launch per wavefront diagonal */
 int64_t mmqg_lstm_seq_persist_ws_bytes(int T, int B, int L, int H);
-/* diagnostics: how many forward time loops this process has run as persistent launches so far */
+/* diagnostics: how many time loops this process has run as persistent launches so far (forward + backward), and how
+ * many requests the in-flight guard has declined (those ran as one launch per diagonal) */
 int mmqg_persist_launch_count(void);
+int mmqg_persist_declined_count(void);
+/* Health of the persistent time loops.  A launch whose device-wide barrier timed out (its workgroups were not all
+ * resident) poisons its output with NaN, bumps a counter in its workspace and sets a word in pinned host memory that
+ * this call reads WITHOUT synchronising (the one host allocation the library makes: 64 bytes, at the first
+ * *_persist_ws_bytes query).  > 0: at least one launch failed; mmqg_lstm_seq_fwd/bwd and mmqg_decoder_seq_fwd/bwd then
+ * return an error (mmqg_last_error() explains) until mmqg_persist_clear_failures().  A caller that replays captured
+ * graphs makes no library call per step: it polls this function (BatchedTrainer.step does). */
+int mmqg_persist_failures(void);
+int mmqg_persist_clear_failures(void);
+/* test hook: the following persistent launches wait for extra_workgroups more arrivals than their grid has and give up
+ * after max_spins polls (0, 0 switches it off) — exercises the failure path without occupying the chip */
+int mmqg_persist_set_test_fault(int extra_workgroups, uint32_t max_spins);
 /* diagnostics: the following persistent launches write 4 wall-clock stamps (100 MHz) per (workgroup, diagonal) into
  * buf[words] (start, products done, cell done, barrier passed); NULL switches it off.  Stamped launches run a
  * separate instantiation of the kernel: the product kernel carries no stamps. */
 int mmqg_persist_set_trace(uint64_t* buf, int64_t words);
 int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_stream stream);
+/* bytes of mmqg_lstm_seq_grad.persist_ws for this shape; 0 = shape not taken (B > 64, H not a multiple of 64 or
+ * below 128, weights beyond the chip's LDS, ...): the backward then runs one launch per anti-diagonal */
+int64_t mmqg_lstm_seq_bwd_persist_ws_bytes(int T, int B, int L, int H);
+/* diagnostics, as mmqg_persist_launch_count / mmqg_persist_set_trace for the backward kernel (6 stamps per
+ * (workgroup, diagonal): start, partial products stored, first barrier passed, gate gradients published, arrived at
+ * the second barrier, second barrier passed) */
+int mmqg_persist_bwd_launch_count(void);
+int mmqg_persist_bwd_set_trace(uint64_t* buf, int64_t words);
 
 /* mmqg_decoder_seq: AttnDecoder.forward (decoder.py:74-107) for T teacher-forced steps
  * (train.py:171-175): per step attention scores, three softmaxes, three contexts, the L-layer

@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmqg_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LAYERS = 8
 
 K_MAJOR, MN_MAJOR = 0, 1
@@ -56,7 +56,8 @@ class LstmSeqGrad(C.Structure):
                 ("dgates", c_f), ("dxl", c_f), ("dh", c_f), ("dc", c_f),
                 ("dx", c_f), ("lddx", C.c_int32),
                 ("dw_ih", _PTRS), ("dw_hh", _PTRS), ("db_ih", _PTRS), ("db_hh", _PTRS),
-                ("dh0", c_f), ("dc0", c_f), ("phase", C.c_int32)]
+                ("dh0", c_f), ("dc0", c_f), ("phase", C.c_int32),
+                ("persist_ws", c_f), ("persist_ws_bytes", c_i64)]
 
 
 class DecoderSeq(C.Structure):
@@ -171,6 +172,13 @@ SIGNATURES = {
     "mmqg_lstm_seq_fwd": [C.POINTER(LstmSeq), c_f],
     "mmqg_lstm_seq_persist_ws_bytes": [C.c_int, C.c_int, C.c_int, C.c_int],
     "mmqg_persist_launch_count": [],
+    "mmqg_lstm_seq_bwd_persist_ws_bytes": [C.c_int, C.c_int, C.c_int, C.c_int],
+    "mmqg_persist_bwd_launch_count": [],
+    "mmqg_persist_bwd_set_trace": [c_f, c_i64],
+    "mmqg_persist_declined_count": [],
+    "mmqg_persist_failures": [],
+    "mmqg_persist_clear_failures": [],
+    "mmqg_persist_set_test_fault": [C.c_int, C.c_uint32],
     "mmqg_persist_set_trace": [c_f, c_i64],
     "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
     "mmqg_decoder_decode_run": [C.POINTER(DecoderDecode), c_f],

@@ -468,7 +468,10 @@ static int attn_context_bwd_impl(const mmqg_attn_values& v, const float* attn, i
     k.blocks_text = ceil_div(v.Lt, kRowBlock);
     k.blocks_audio = ceil_div(v.Lav, kRowBlock);
     k.blocks_video = ceil_div(v.Lav, kRowBlock);
-    const bool g_ok = aligned16(dctx) && (ld_c % 4 == 0) && (v.H % 4 == 0) && (v.Da % 4 == 0);
+    // the fused form also reads the saved contexts with 16-byte loads: they are an operand of their own (public
+    // entry point: ctx / ld_x are independent of dctx / ld_c)
+    const bool g_ok = aligned16(dctx) && (ld_c % 4 == 0) && (v.H % 4 == 0) && (v.Da % 4 == 0) &&
+                      (!ctx || (aligned16(ctx) && ld_x % 4 == 0));
     k.vec_text = g_ok && vec_ok(v.text, v.text_stride_b, v.H);
     k.vec_audio = g_ok && vec_ok(v.audio, v.audio_stride_b, v.Da);
     k.vec_video = g_ok && vec_ok(v.video, v.video_stride_b, v.Dv);

@@ -170,13 +170,26 @@ int mmqg_transpose_f32_batch(const mmqg_transpose_job* jobs, int n, mmqg_stream 
 
 int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream) {
     MMQG_REQUIRE(d, "mmqg_lstm_seq_fwd: null descriptor");
+    MMQG_TRY(persist_check_healthy("mmqg_lstm_seq_fwd"));
     return lstm_seq_fwd(*d, S(stream));
 }
 int64_t mmqg_lstm_seq_persist_ws_bytes(int T, int B, int L, int H) { return lstm_persist_ws_bytes(T, B, L, H); }
 int mmqg_persist_launch_count(void) { return persist_launch_count(); }
+int64_t mmqg_lstm_seq_bwd_persist_ws_bytes(int T, int B, int L, int H) { return lstm_persist_bwd_ws_bytes(T, B, L, H); }
+int mmqg_persist_bwd_launch_count(void) { return persist_bwd_launch_count(); }
+int mmqg_persist_bwd_set_trace(uint64_t* buf, int64_t words) { persist_bwd_set_trace(reinterpret_cast<unsigned long long*>(buf), words); return 0; }
+int mmqg_persist_declined_count(void) { return persist_declined_count(); }
+int mmqg_persist_failures(void) { return persist_failures(); }
+int mmqg_persist_clear_failures(void) { persist_clear_failures(); return 0; }
+int mmqg_persist_set_test_fault(int extra_workgroups, uint32_t max_spins) {
+    MMQG_REQUIRE(extra_workgroups >= 0, "persist_set_test_fault: extra_workgroups must be >= 0");
+    persist_set_test_fault(extra_workgroups, max_spins);
+    return 0;
+}
 int mmqg_persist_set_trace(uint64_t* buf, int64_t words) { persist_set_trace(reinterpret_cast<unsigned long long*>(buf), words); return 0; }
 int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_stream stream) {
     MMQG_REQUIRE(d && g, "mmqg_lstm_seq_bwd: null descriptor");
+    MMQG_TRY(persist_check_healthy("mmqg_lstm_seq_bwd"));
     return lstm_seq_bwd(*d, *g, S(stream));
 }
 int mmqg_frame_cnn_fwd(const mmqg_frame_cnn* d, mmqg_stream stream) {
@@ -189,6 +202,7 @@ int mmqg_frame_cnn_bwd(const mmqg_frame_cnn* d, const mmqg_frame_cnn_grad* g, mm
 }
 int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream) {
     MMQG_REQUIRE(d, "mmqg_decoder_seq_fwd: null descriptor");
+    MMQG_TRY(persist_check_healthy("mmqg_decoder_seq_fwd"));
     return decoder_seq_fwd(*d, S(stream));
 }
 int mmqg_decoder_decode_run(const mmqg_decoder_decode* d, mmqg_stream stream) {
@@ -201,6 +215,7 @@ int mmqg_sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t se
 }
 int mmqg_decoder_seq_bwd(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g, mmqg_stream stream) {
     MMQG_REQUIRE(d && g, "mmqg_decoder_seq_bwd: null descriptor");
+    MMQG_TRY(persist_check_healthy("mmqg_decoder_seq_bwd"));
     return decoder_seq_bwd(*d, *g, S(stream));
 }
 

@@ -13,9 +13,11 @@
 // sync() before the workgroup barrier), and every LOAD of such data must be an sc1 load (raw_buffer_load ...
 // aux 16) — cdna_hip_programming.md Guideline 16, recipe R1 with sc1 loads in place of the acquire.
 //
-// Every spin is bounded; on a timeout the fail word is set, every workgroup leaves at its next poll and
-// sync() returns false.  The XBar block must be zero when the kernel starts, and the whole grid must be
-// resident (grid <= number of CUs, one workgroup fitting a CU).
+// Every spin is bounded (Ctx::max_spins polls); on a timeout the fail word is set, every workgroup leaves at its
+// next poll and sync() returns false; a leader whose wait failed does NOT release its XCC (its peers leave through
+// the fail word), so nobody runs on past a failed barrier.  The XBar block must be zero when the kernel starts,
+// and the whole grid must be resident (grid <= number of CUs, one workgroup fitting a CU).  report_failure() makes
+// the failure visible to the host: a sticky counter in device memory and a word in pinned host memory.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,30 +46,37 @@ __device__ __forceinline__ u32 ld_rlx(u32* p) { return __hip_atomic_load(p, __AT
 __device__ __forceinline__ void st_rlx(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u32 add_rlx(u32* p, u32 v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ bool spin_until_ge(u32* p, u32 target, u32* fail) {
+constexpr u32 kDefaultSpins = 1u << 22;     // polls (each an s_sleep + an L2 round trip: seconds in all)
+
+__device__ __forceinline__ bool spin_until_ge(u32* p, u32 target, u32* fail, u32 max_spins) {
     u32 spins = 0;
     while ((int)(ld_rlx(p) - target) < 0) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 22) || ((spins & 255u) == 0 && ld_rlx(fail))) { st_rlx(fail, 1u); return false; }
+        if (++spins > max_spins || ((spins & 255u) == 0 && ld_rlx(fail))) { st_rlx(fail, 1u); return false; }
     }
     return true;
 }
 
 struct Ctx {
     XBar* b;
-    u32 x, n_x, n_groups, k, leader;
+    u32 x, n_x, n_groups, k, leader, max_spins;
 };
 
 // census of the workgroups per XCC (placement is whatever the dispatcher chose) + one flat barrier
-__device__ __forceinline__ bool init(Ctx& c, XBar* b, u32 n_workgroups) {
+__device__ __forceinline__ bool init(Ctx& c, XBar* b, u32 n_workgroups, u32 max_spins = kDefaultSpins) {
     c.b = b;
     c.x = xcc_id();
     c.k = 0;
+    c.max_spins = max_spins;
     bool ok = true;
     if (threadIdx.x == 0) {
-        add_rlx(&b->census[c.x * kLine], 1u);
+        // the census add must be PERFORMED before this workgroup counts in the flat barrier: whoever sees
+        // flat == n_workgroups reads the census next.  The returned value is made a register operand of an (empty)
+        // asm statement, so hipcc waits for the atomic's return before it issues the flat add.
+        const u32 seen = add_rlx(&b->census[c.x * kLine], 1u);
+        asm volatile("; census add returned" ::"v"(seen) : "memory");
         add_rlx(&b->flat[0], 1u);
-        ok = spin_until_ge(&b->flat[0], n_workgroups, b->fail);
+        ok = spin_until_ge(&b->flat[0], n_workgroups, b->fail, c.max_spins);
     }
     ok = __syncthreads_and(ok);
     c.n_x = ld_rlx(&b->census[c.x * kLine]);
@@ -103,10 +112,10 @@ __device__ __forceinline__ bool wait(Ctx& c) {
     if (threadIdx.x == 0) {
         XBar* b = c.b;
         if (c.leader) {
-            ok = spin_until_ge(&b->top[0], c.k * c.n_groups, b->fail);
-            st_rlx(&b->xcc_gen[c.x * kLine], c.k);
+            ok = spin_until_ge(&b->top[0], c.k * c.n_groups, b->fail, c.max_spins);
+            if (ok) st_rlx(&b->xcc_gen[c.x * kLine], c.k);     // a failed wait releases nobody: peers leave via the fail word
         } else {
-            ok = spin_until_ge(&b->xcc_gen[c.x * kLine], c.k, b->fail);
+            ok = spin_until_ge(&b->xcc_gen[c.x * kLine], c.k, b->fail, c.max_spins);
         }
     }
     return __syncthreads_and(ok);
@@ -115,6 +124,16 @@ __device__ __forceinline__ bool wait(Ctx& c) {
 __device__ __forceinline__ bool sync(Ctx& c) {
     arrive(c);
     return wait(c);
+}
+
+// A workgroup that left a barrier with ok == false tells the host (one lane): `sticky` is a device counter that
+// nothing resets between launches, `host` (nullable) a word in pinned host memory the library polls without
+// synchronising.
+__device__ __forceinline__ void report_failure(u32* sticky, u32* host) {
+    if (threadIdx.x == 0) {
+        add_rlx(sticky, 1u);
+        if (host) __hip_atomic_store(host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace gb

@@ -143,6 +143,25 @@ int64_t lstm_persist_ws_bytes(int T, int B, int L, int H);
 // 0 = done, 1 = not eligible (caller falls back to one launch per diagonal), < 0 = error
 int lstm_seq_fwd_persistent(const mmqg_lstm_seq& d, hipStream_t s);
 int persist_launch_count();
+// persist_bwd.hip: the backward time loop of an LSTM stack as one persistent launch
+bool lstm_persist_bwd_shape_ok(int T, int B, int L, int H);
+int64_t lstm_persist_bwd_ws_bytes(int T, int B, int L, int H);
+int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s);
+int persist_bwd_launch_count();
+void persist_bwd_set_trace(unsigned long long* buf, int64_t words);
+// persist_rt.hip: who may launch a persistent kernel, and how a failed one reaches the host
+void persist_runtime_prepare();
+int persist_device_cus();
+unsigned* persist_host_fail_word();
+int persist_begin(hipStream_t s);        // 0 = granted, 1 = declined (another persistent launch may be in flight)
+void persist_end(hipStream_t s);
+int persist_declined_count();
+int persist_failures();
+void persist_clear_failures();
+int persist_check_healthy(const char* who);
+void persist_set_test_fault(int extra_workgroups, unsigned max_spins);
+int persist_test_extra_wg();
+unsigned persist_test_max_spins();
 
 // ---- cnn.hip --------------------------------------------------------------------------
 int frame_cnn_fwd(const mmqg_frame_cnn& d, hipStream_t s);

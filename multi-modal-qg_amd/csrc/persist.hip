@@ -57,6 +57,9 @@ struct PersistArgs {
     float* xd;            // [L-1][2][H/4][64][4] dropped h(t) for the layer above (only when dropout is live)
     gb::XBar* bar;
     float* poison;        // receives NaN when a barrier times out
+    unsigned* sticky_fail;   // device counter of failed launches (never reset by the library), in the workspace
+    unsigned* host_fail;     // pinned host word the library polls without synchronising (nullable)
+    unsigned expect_wg, max_spins;   // workgroups the barrier waits for (= gridDim.x; the test hook adds to it) / spin bound
     unsigned long long* trace;   // diagnostics (tools/persist_trace.py): [workgroup][diagonal][4] wall-clock stamps, or null
 };
 
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_fwd_kernel(PersistAr
     }
 
     gb::Ctx bar;
-    bool ok = gb::init(bar, a.bar, gridDim.x);
+    bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
     if (ok) ok = gb::sync(bar);                   // weights are in LDS (workgroup-local), h(-1) is published
     // the second-dispatched half of an 8-wave workgroup loses the issue arbitration on every SIMD to its older partner
     // (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority for waves 4-7 evens the two halves out
@@ -355,7 +358,10 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_fwd_kernel(PersistAr
         ok = gb::wait(bar);
         MMQG_PSTAMP(5)
     }
-    if (!ok && tid == 0) a.poison[0] = __builtin_nanf("");
+    if (!ok) {            // a barrier timed out (not every workgroup resident, or the test hook): loud, not silent
+        gb::report_failure(a.sticky_fail, a.host_fail);
+        if (tid == 0) a.poison[0] = __builtin_nanf("");
+    }
 }
 #undef MMQG_PSTAMP
 
@@ -415,25 +421,16 @@ bool build_plan(int L, int H, int B, int G, Plan& plan, int& max_lds_bytes) {
     return true;
 }
 
-int device_cus() {
-    static const int n = [] {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-        return p.multiProcessorCount;
-    }();
-    return n;
-}
-
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-struct WsLayout { int64_t bar, hx, xd, total; };
+struct WsLayout { int64_t bar, hx, xd, sticky, total; };
 WsLayout ws_layout(int L, int H) {
     WsLayout w;
     w.bar = 0;
     w.hx = align_up((int64_t)sizeof(gb::XBar), 256);
     w.xd = w.hx + (int64_t)L * 2 * kRows * H * 4;
-    w.total = w.xd + (int64_t)std::max(L - 1, 1) * 2 * kRows * H * 4;
+    w.sticky = w.xd + (int64_t)std::max(L - 1, 1) * 2 * kRows * H * 4;   // failure counter: zeroed by the CALLER, once
+    w.total = w.sticky + 256;
     return w;
 }
 
@@ -457,6 +454,7 @@ bool lstm_persist_shape_ok(int T, int B, int L, int H) {
 
 int64_t lstm_persist_ws_bytes(int T, int B, int L, int H) {
     if (!lstm_persist_shape_ok(T, B, L, H)) return 0;
+    persist_runtime_prepare();           // pinned failure word + event: outside any stream capture
     return ws_layout(L, H).total;
 }
 
@@ -467,7 +465,7 @@ int lstm_seq_fwd_persistent(const mmqg_lstm_seq& d, hipStream_t s) {
     if (d.persist_ws_bytes < wl.total || !aligned16(d.persist_ws)) return 1;
     for (int l = 0; l < d.L; ++l)
         if (!aligned16(d.w_hh[l]) || (l > 0 && !aligned16(d.w_ih[l]))) return 1;
-    const int cus = device_cus();
+    const int cus = persist_device_cus();
     const int G = std::min(cus, kMaxWG);
     if (G < 64) return 1;
     Plan plan;
@@ -484,6 +482,19 @@ int lstm_seq_fwd_persistent(const mmqg_lstm_seq& d, hipStream_t s) {
         attr_set = e == hipSuccess ? 1 : -1;
     }
     if (attr_set < 0) return 1;
+    {   // the grid is one workgroup per CU: the kernel must fit a CU with this much LDS (checked once per size)
+        static int occ_lds = -1, occ_ok = 0;
+        if (occ_lds != lds_bytes) {
+            int nb = 0;
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &nb, reinterpret_cast<const void*>(lstm_persist_fwd_kernel<false>), kThreads, (size_t)lds_bytes);
+            if (e != hipSuccess) (void)hipGetLastError();
+            occ_lds = lds_bytes; occ_ok = (e == hipSuccess && nb >= 1) ? 1 : 0;
+        }
+        if (!occ_ok) return 1;
+    }
+    // no two persistent launches in flight on one device (persist_rt.hip): declined -> one launch per diagonal
+    if (persist_begin(s) != 0) return 1;
 
     const int T = d.T, B = d.B, H = d.H, L = d.L;
     const int64_t BH = (int64_t)B * H;
@@ -510,11 +521,16 @@ int lstm_seq_fwd_persistent(const mmqg_lstm_seq& d, hipStream_t s) {
     a.hx = reinterpret_cast<float*>(ws + wl.hx);
     a.xd = reinterpret_cast<float*>(ws + wl.xd);       // directly behind hx: one buffer descriptor covers both
     a.poison = d.hs + ((int64_t)(L - 1) * (T + 1) + T) * BH;        // final h of the top layer
+    a.sticky_fail = reinterpret_cast<unsigned*>(ws + wl.sticky);
+    a.host_fail = persist_host_fail_word();
+    a.expect_wg = (unsigned)(G + persist_test_extra_wg());
+    a.max_spins = persist_test_max_spins() ? persist_test_max_spins() : gb::kDefaultSpins;
     a.trace = nullptr;
     if (g_trace_buf && (int64_t)G * (T + L - 1) * 6 <= g_trace_words) a.trace = g_trace_buf;
     if (a.trace) hipLaunchKernelGGL(lstm_persist_fwd_kernel<true>, dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a, plan);
     else hipLaunchKernelGGL(lstm_persist_fwd_kernel<false>, dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a, plan);
     g_persist_launches += 1;
+    persist_end(s);
     return check_launch("lstm_persist_fwd");
 }
 

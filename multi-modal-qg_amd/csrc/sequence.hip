@@ -254,6 +254,22 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
     MMQG_REQUIRE(g.phase >= 0 && g.phase <= 2, "lstm_seq_bwd: phase must be 0, 1 or 2");
     const bool do_wgrad = g.phase != 1;
     bool do_loop = g.phase != 2;
+    if (do_loop && g.persist_ws && !g_no_fuse()) {      // all anti-diagonals as one persistent launch (persist_bwd.hip)
+        const int rc = lstm_seq_bwd_persistent(d, g, s);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            do_loop = false;
+            // gradient of the initial state: what the kernel left in dh (carry) + dgates_l(0) * W_hh_l
+            for (int l = 0; l < L && (g.dh0 || g.dc0); ++l) {
+                if (g.dh0) {
+                    MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, 4 * H, g.dgates + (int64_t)l * T * G, 4 * H, d.w_hh[l],
+                                      H, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 1, g.dh + l * BH, H, -1, s));
+                    MMQG_TRY(copy_or_zero(g.dh0 + l * BH, g.dh + l * BH, (size_t)BH, s));
+                }
+                if (g.dc0) MMQG_TRY(copy_or_zero(g.dc0 + l * BH, g.dc + l * BH, (size_t)BH, s));
+            }
+        }
+    }
     if (do_loop && lstm_wavefront_bwd_ok(d, g)) {
         MMQG_TRY(lstm_seq_bwd_wavefront(d, g, s));
         do_loop = false;

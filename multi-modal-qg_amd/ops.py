@@ -329,6 +329,9 @@ class LSTMSeqFn(torch.autograd.Function):
         g.dgates, g.dxl, g.dh, g.dc = dgates.data_ptr(), dxl.data_ptr(), dh.data_ptr(), dc.data_ptr()
         g.dx, g.lddx = dx.data_ptr(), In
         g.dh0, g.dc0 = dh0.data_ptr(), dc0.data_ptr()
+        nws = int(_lib.load().mmqg_lstm_seq_bwd_persist_ws_bytes(T, B, L, H))   # > 0: the persistent backward takes this shape
+        bws = torch.zeros((nws + 3) // 4, device=dev, dtype=torch.float32) if nws > 0 else None
+        g.persist_ws, g.persist_ws_bytes = ptr(bws), nws
         dparams = [torch.zeros_like(p) for p in params]
         for l in range(L):
             g.dw_ih[l], g.dw_hh[l], g.db_ih[l], g.db_hh[l] = (p.data_ptr() for p in dparams[4 * l:4 * l + 4])

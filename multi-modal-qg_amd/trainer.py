@@ -244,7 +244,9 @@ class BatchedTrainer:
         gv.dx, gv.lddx = w["dfeats"].data_ptr(), self.Fin
         dv.w_hhT[0] = w["whhT_v"].data_ptr()
         # (no persistent time loop for the frame LSTM: it runs on the side stream BESIDE the text encoder's, and two
-        # persistent launches that cannot share a CU may each end up half resident and wait for the other forever)
+        # persistent launches that cannot share a CU may each end up half resident and wait for the other forever;
+        # the library enforces that — csrc/persist_rt.hip declines the second request of a capture's other stream —
+        # so asking would only cost the declined attempt)
         self.d_vid, self.g_vid = dv, gv
         # text encoder -> text rows of the value tensor
         dt, gt = _lib.LstmSeq(), _lib.LstmSeqGrad()
@@ -265,6 +267,10 @@ class BatchedTrainer:
             if l > 0:
                 dt.w_ihT[l] = w["wihT_t"][l].data_ptr()
         self._persist_ws(dt, "pws_t")
+        n = int(_lib.load().mmqg_lstm_seq_bwd_persist_ws_bytes(dt.T, dt.B, dt.L, dt.H))
+        if n > 0:         # the backward time loop as one persistent launch too (csrc/persist_bwd.hip)
+            w["pws_tb"] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)
+            gt.persist_ws, gt.persist_ws_bytes = w["pws_tb"].data_ptr(), n
         self.d_text, self.g_text = dt, gt
         # decoder
         dd, gd = _lib.DecoderSeq(), _lib.DecoderSeqGrad()
@@ -694,8 +700,31 @@ class BatchedTrainer:
         if self._cnn_on and self.training:                      # BatchNorm2d.num_batches_tracked: one per question
             torch._foreach_add_([getattr(self.video, f"bn{i}").num_batches_tracked for i in (1, 2, 3, 4)], self.B)
 
+    def check_health(self, sync: bool = False) -> None:
+        """Raise if a persistent time loop of this process timed out at its device-wide barrier (its workgroups were
+        not all resident).  The kernels report that through a word in pinned host memory, so this costs a host read;
+        ``sync=True`` first waits for the device (use it before checkpointing or trusting a loss)."""
+        if sync:
+            torch.cuda.synchronize(self.dev)
+        lib = _lib.load()
+        if lib.mmqg_persist_failures() > 0:
+            raise _lib.BackendError(
+                "mmqg: a persistent time loop timed out at a device-wide barrier (another persistent launch or another "
+                "process on this device kept part of its grid off the CUs); its outputs were poisoned with NaN and the "
+                "parameters may have been updated from them — restore the last checkpoint.  MMQG_NO_PERSIST=1 selects "
+                "the launch-per-diagonal time loops.")
+
+    def loss_value(self) -> float:
+        """The last step's loss as a float: waits for the device, then checks the health word and finiteness."""
+        v = float(self.ws["loss"])
+        self.check_health()
+        if v != v:
+            raise _lib.BackendError("mmqg: the loss is NaN")
+        return v
+
     def step(self, batch: Optional[dict] = None):
         """One full training iteration (train.py:149-181).  Returns the loss tensor (device)."""
+        self.check_health()         # a failure of an EARLIER step (the word is written asynchronously): stop before the next update
         if self.use_graph and batch is not None:
             return self._graph_step(batch)
         loss = self.forward_backward(batch)

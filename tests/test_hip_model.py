@@ -405,7 +405,7 @@ def test_eval_mode_forward_then_backward_gives_the_same_gradients(mm):
 
 
 def _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode, tol=TOL, wtol=2e-6, well_conditioned_only=True,
-                               eval_mode=False):
+                               eval_mode=False, check_logits=False):
     """well_conditioned_only: the first Adam step is lr*g/(|g|+eps), ill-conditioned where |g| ~ eps = 1e-8 (fp32
     noise in g of 1e-9 moves such a weight by a percent of lr), so the tight weight bound is applied to the elements
     whose gradient is not tiny (|g| > 1e-3 max|g|); for the rest only |difference| <= 2*lr holds by construction."""
@@ -432,6 +432,12 @@ def _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode, tol=TOL, wto
     want_loss, want_logits = ot.step({k: (v.long() if v.dtype == torch.int32 else v) for k, v in batch.items()},
                                      training=not eval_mode, drop=drop)
     grads = {id(t): t.grad.clone() for t in ot.trainable() if t.grad is not None}
+    if check_logits:      # per-question logits of every valid step (the forward does not advance the dropout counter)
+        got_logits = tr.forward_only(batch, training=not eval_mode).cpu()
+        for b in range(B):
+            n = int(batch["tgt_len"][b])
+            close(got_logits[b, :n], want_logits[b, :n], tol=tol, what=f"logits of question {b}")
+        assert _argmax_ties_only(got_logits, want_logits, batch["tgt_len"].cpu()), "teacher-forced argmax ids differ"
     loss = tr.forward_backward(batch)
     close(loss.view(()), np.float32(want_loss), tol=tol, what="loss")
     for mod, osd in ((dec, sd[0]), (text, sd[1]), (vid, sd[2])):
@@ -449,6 +455,79 @@ def _check_step_against_oracle(mm, w, batch, B, dropout, mask_mode, tol=TOL, wto
                 assert worst <= 2.002e-4, f"weight {k} after Adam: {worst:.3e} exceeds two Adam steps of lr = 1e-4"
             else:
                 close(p, osd[k], tol=wtol, what=f"weight {k} after Adam")
+
+
+def _argmax_ties_only(got, want, tgt_len, margin=1e-4):
+    """Teacher-forced argmax ids are bit-exact unless the oracle's top two logits are closer than the fp32 parity bar."""
+    Td = got.shape[1]
+    valid = tgt_len.view(-1, 1) > torch.arange(Td)
+    ga, wa = got.argmax(-1), want.argmax(-1)
+    bad = valid & (ga != wa)
+    if not bool(bad.any()):
+        return True
+    top2 = want.topk(2, dim=-1).values
+    gap = (top2[..., 0] - top2[..., 1]).abs()
+    scale = want.abs().amax(-1)
+    return bool((gap[bad] <= margin * scale[bad]).all())
+
+
+@pytest.mark.parametrize("name,B,ragged", [("config2", 64, False), ("config2", 64, True), ("config4", 32, True),
+                                           ("config5", 128, True)])
+def test_bench_size_step_matches_oracle(mm, name, B, ragged):
+    """The assembled step at the batch sizes bench.py runs: config 2 at B = 64 (the bench's own
+    rectangular batch and a ragged one), config 4 at B = 32, config 5 at B = 128 — the sizes at which the
+    split-bf16 grouped products, the persistent 4-row-block time loop, the wide forward layer-step kernel and the
+    k-sliced weight gradients are the kernels that run.  Dropout live (masks replayed into the oracle): per-question
+    logits, loss, EVERY gradient, weights after Adam, against the batched CPU oracle."""
+    from mmqg_amd.synthetic import WORKLOADS, synthetic_batch
+    from mmqg_amd import _lib
+    w = WORKLOADS[name]
+    batch = synthetic_batch(w, seed=0 if not ragged else 23, batch=B, ragged=ragged)
+    before = _lib.load().mmqg_persist_launch_count()
+    _check_step_against_oracle(mm, w, batch, B, w.dropout, 0, tol=1e-4, wtol=5e-6, well_conditioned_only=True,
+                               check_logits=True)
+    if name in ("config2", "config4") and os.environ.get("MMQG_NO_PERSIST", "0") != "1":
+        assert _lib.load().mmqg_persist_launch_count() > before, "the persistent time loop did not run at bench size"
+
+
+def test_kernel_families_give_the_same_gradients_at_bench_size(mm, tmp_path):
+    """Every A/B family of the step (fp32-MFMA products instead of split-bf16, launch-per-diagonal instead of the
+    persistent time loops, 16x16 layer-step tiles instead of the wide kernel, the captured graph instead of eager
+    launches) must give the same loss, logits and FULL gradient at the bench's batch size: each family is checked
+    against the oracle on its own at small batch, the default one also at bench size (test above)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base_env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+                and not k.startswith("MMQG_")}
+
+    def run(tag, workload, B, env=None, extra=()):
+        out = str(tmp_path / f"{workload}_{tag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "step_dump.py"), "--workload", workload, "--batch",
+                            str(B), "--out", out, *extra], env={**base_env, **(env or {})}, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return np.load(out)
+
+    for workload, B, variants in (
+            ("config2", 64, [("x3off", {"MMQG_GEMM_X3": "0"}, ()), ("nopersist", {"MMQG_NO_PERSIST": "1"}, ()),
+                             ("nofuse", {"MMQG_NO_FUSE": "1"}, ()), ("graph", {}, ("--graph",))]),
+            ("config5", 128, [("x3off", {"MMQG_GEMM_X3": "0"}, ()), ("nowide", {"MMQG_NO_WIDE": "1"}, ())])):
+        ref = run("default", workload, B)
+        assert int(ref["projection_kernel"]) == 2, "the default step must take the split-bf16 projection"
+        if workload == "config2":
+            assert int(ref["persist_launches"]) > 0
+        for tag, env, extra in variants:
+            got = run(tag, workload, B, env, extra)
+            if tag == "x3off":
+                assert int(got["projection_kernel"]) != 2
+            if tag in ("nopersist", "nofuse"):
+                assert int(got["persist_launches"]) == 0
+            close(got["loss"], ref["loss"], tol=1e-5, what=f"{workload} {tag}: loss vs default")
+            close(got["logits"], ref["logits"], tol=2e-5, what=f"{workload} {tag}: logits vs default")
+            for k in ref.files:
+                if k.startswith("grad_"):
+                    close(got[k], ref[k], tol=5e-5, what=f"{workload} {tag}: {k} vs default")
 
 
 def test_skipping_zero_padded_value_rows_changes_nothing(mm):
@@ -741,26 +820,3 @@ def test_bench_self_launch_runs_a_rank_through_rccl(mm):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["world_size"] == 1 and "nccl" in d["config"]["collective_backend"]
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["roofline"]["achieved_beyond_mall"] > 0
-
-
-def test_fp32_matrix_core_kernels_give_the_same_training_step(mm):
-    """The large products run on the bf16 matrix cores with exactly split fp32 operands (csrc/gemm_x3.hip); with
-    MMQG_GEMM_X3=0 they run on the fp32 MFMA kernels.  Both are fp32 arithmetic: after the same five training steps
-    of config 2 (dropout live, same seeds) the two losses agree to 1e-5 relative — and the fallback family keeps
-    being exercised."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    losses = {}
-    for x3 in ("1", "0"):
-        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-        env["MMQG_GEMM_X3"] = x3
-        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2",
-                            "--no-cpu-baseline", "--kernel-iters", "5"], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-        losses[x3] = d["final_loss"]
-        want = "gemm_x3pp" if x3 == "1" else "gemm_nt_tile"
-        assert want in d["roofline_mfma"]["kernel"], d["roofline_mfma"]["kernel"]
-    assert abs(losses["1"] - losses["0"]) <= 1e-5 * abs(losses["0"]), losses

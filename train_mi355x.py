@@ -54,7 +54,7 @@ def run_synthetic(a, world, rank, dev):
             torch.cuda.synchronize(); t0, i0 = time.perf_counter(), i
         loss = tr.step(batches[i % len(batches)])
         if rank == 0 and (i % a.log_every == 0 or i == a.steps - 1):
-            print(f"step {i:5d}  loss/token {float(loss) / w.tgt_len:.4f}", flush=True)
+            print(f"step {i:5d}  loss/token {tr.loss_value() / w.tgt_len:.4f}", flush=True)
     torch.cuda.synchronize()
     if rank == 0 and t0 is not None and a.steps - i0 > 0:
         dt = time.perf_counter() - t0
@@ -134,7 +134,7 @@ def run_real(a, world, rank, dev):
         tot, n = 0.0, 0
         for batch in train_batches(epoch):
             loss = tr.step({k: v for k, v in batch.items() if torch.is_tensor(v)})
-            tot += float(loss) / max(1.0, float(batch["tgt_len"].float().mean())); n += 1
+            tot += tr.loss_value() / max(1.0, float(batch["tgt_len"].float().mean())); n += 1
         tr.eval()
         sync_bn_buffers()
         # validate() (train.py:61-129): per question loss / target_len and the four BLEU numbers, averaged over
@@ -148,6 +148,7 @@ def run_real(a, world, rank, dev):
                 pred = ids_to_words(truncate_at_end(out["ids"][b].tolist(), end_id), val_ds.index_to_word)
                 for k, v in reference_bleu_scores(batch["question"][b], pred).items():
                     bleu[k] += v
+        tr.check_health(sync=True)            # never checkpoint behind a failed persistent launch
         tot, n, vloss, m, *bl = all_sum([tot, n, vloss, m] + [bleu[k] for k in bleu_keys])
         val_loss = vloss / max(m, 1.0)
         if rank == 0:
