@@ -99,6 +99,16 @@ typedef struct {
  * ctx [B][ld_c] = text ctx (H) | audio ctx (Da) | video ctx (Dv). */
 int mmqg_attn_softmax_context_fwd(const mmqg_attn_values* v, const float* scores, int ld_s,
                                   float* attn, int ld_a, float* ctx, int ld_c, mmqg_stream stream);
+/* The training loop's form: score product + softmax + context in ONE launch (decoder.py:78-95 for a teacher-forced
+ * step whose embedded-word half of the scores is hoisted).  scores = pre [B][ld_s] (hoisted half + bias, left
+ * untouched) + h [B][ld_h] (Hq wide: h_top of the previous step) x W^T, W = the recurrent half of the stacked score
+ * matrix, row s at W + s * ld_w (Hq floats); attn / ctx as above.  ws: mmqg_attn_fused_ws_bytes(v, Hq) bytes, 16-byte
+ * aligned, ZERO-FILLED ONCE by the caller (tickets at its end; the kernel leaves them zero).  Returns 0 = launched,
+ * 1 = shape / alignment not taken (run the score product and mmqg_attn_softmax_context_fwd instead), < 0 = error. */
+int64_t mmqg_attn_fused_ws_bytes(const mmqg_attn_values* v, int Hq);
+int mmqg_attn_scores_softmax_context_fwd(const mmqg_attn_values* v, const float* pre, int ld_s, const float* h, int ld_h,
+                                         const float* W, int ld_w, int Hq, float* attn, int ld_a, float* ctx, int ld_c,
+                                         float* ws, int64_t ws_bytes, mmqg_stream stream);
 /* dscores[b] = softmax'(attn[b]) applied to d(attn) = values . dctx (+ dattn, the gradient of
  * the returned attention weights themselves, nullable) */
 int mmqg_attn_context_bwd(const mmqg_attn_values* v, const float* attn, int ld_a,
@@ -317,6 +327,9 @@ typedef struct {
                                                        xemb); 2 = state init + time loop (after phase 1) */
     int64_t h0_stride_l;                            /* elements between the layers of h0 / c0; 0 = B*H.  Lets h0/c0
                                                        point at the final slot of an encoder's hs/cs (train.py:169) */
+    float* attn_ws; int64_t attn_ws_bytes;          /* optional workspace (mmqg_attn_fused_ws_bytes(&values, H), zero-filled
+                                                       once): the per-step score product, softmax and contexts then run
+                                                       as ONE launch (mmqg_attn_scores_softmax_context_fwd) */
 } mmqg_decoder_seq;
 
 typedef struct {

@@ -71,7 +71,7 @@ class DecoderSeq(C.Structure):
                 ("seed_offset", c_f),
                 ("scores", c_f), ("attn", c_f), ("ld_attn", C.c_int32),
                 ("ctx", c_f), ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f), ("phase", C.c_int32),
-                ("h0_stride_l", c_i64)]
+                ("h0_stride_l", c_i64), ("attn_ws", c_f), ("attn_ws_bytes", c_i64)]
 
 
 class DecoderDecode(C.Structure):
@@ -150,6 +150,9 @@ SIGNATURES = {
     "mmqg_embedding_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mmqg_embedding_bwd": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f],
     "mmqg_attn_softmax_context_fwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f],
+    "mmqg_attn_fused_ws_bytes": [C.POINTER(AttnValues), c_i],
+    "mmqg_attn_scores_softmax_context_fwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_i, c_f, c_i, c_f, c_i,
+                                             c_f, c_i64, c_f],
     "mmqg_attn_context_bwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f],
     "mmqg_attn_context_bwd_fused": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f, c_i, c_f],
     "mmqg_attn_dvalues": [c_i, c_i, c_i, c_i, c_f, c_i64, c_i, c_i, c_f, c_i64, c_i, c_i, c_f, c_i64, c_i64, c_i, c_f],

@@ -67,6 +67,14 @@ int mmqg_attn_softmax_context_fwd(const mmqg_attn_values* v, const float* scores
     MMQG_REQUIRE(v, "mmqg_attn_softmax_context_fwd: null descriptor");
     return attn_softmax_context_fwd(*v, scores, ld_s, attn, ld_a, ctx, ld_c, S(stream));
 }
+int64_t mmqg_attn_fused_ws_bytes(const mmqg_attn_values* v, int Hq) { return v ? attn_fused_ws_bytes(*v, Hq) : 0; }
+int mmqg_attn_scores_softmax_context_fwd(const mmqg_attn_values* v, const float* pre, int ld_s, const float* h, int ld_h,
+                                         const float* W, int ld_w, int Hq, float* attn, int ld_a, float* ctx, int ld_c,
+                                         float* ws, int64_t ws_bytes, mmqg_stream stream) {
+    MMQG_REQUIRE(v, "mmqg_attn_scores_softmax_context_fwd: null descriptor");
+    MMQG_REQUIRE(pre && h && W && attn && ctx, "mmqg_attn_scores_softmax_context_fwd: null pointer");
+    return attn_fused_fwd(*v, pre, ld_s, h, ld_h, W, ld_w, Hq, attn, ld_a, ctx, ld_c, ws, ws_bytes, S(stream));
+}
 int mmqg_attn_context_bwd(const mmqg_attn_values* v, const float* attn, int ld_a, const float* dctx, int ld_c,
                           const float* dattn, int ld_da, float* dscores, int ld_ds, mmqg_stream stream) {
     MMQG_REQUIRE(v, "mmqg_attn_context_bwd: null descriptor");

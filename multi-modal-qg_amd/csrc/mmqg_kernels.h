@@ -112,6 +112,11 @@ int attn_dvalues(int T, int B, int n_rows, int D, const float* attn, int64_t att
                  const float* dctx, int64_t dctx_stride_t, int ld_c, int ctx_off, float* out, int64_t out_stride_row,
                  int64_t out_stride_b, int accumulate, hipStream_t s);
 
+// attention_fused.hip: score product + softmax + context in one launch (0 = launched, 1 = not taken, < 0 = error)
+int64_t attn_fused_ws_bytes(const mmqg_attn_values& v, int Hq);
+int attn_fused_fwd(const mmqg_attn_values& v, const float* pre, int ld_s, const float* h, int ld_h, const float* W, int ld_w,
+                   int Hq, float* attn, int ld_a, float* ctx, int ld_c, float* ws, int64_t ws_bytes, hipStream_t s);
+
 // ---- embedding.hip --------------------------------------------------------------------
 int embedding_fwd(const float* table, const int64_t* ids, float* out, int n, int V, int E, int ld_out, hipStream_t s);
 int embedding_bwd(const float* dout, int ld, const int64_t* ids, float* dtable, int n, int V, int E, hipStream_t s);

@@ -397,14 +397,22 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
         float* sc = d.scores + (int64_t)t * B * ldS;
         float* at = d.attn + (int64_t)t * B * ldS;
         float* cx = d.ctx + (int64_t)t * B * C;
-        // scores += h_top(t-1) * W_attn[:, E:]^T     (decoder.py:78,84,92: query = [emb | h_top])
-        const SkinnyPair spr{htop_base + t * BH, H, d.w_attn + E, Q, H, 0};
-        if (!g_no_fuse() && skinny_usable(&spr, 1))
-            MMQG_TRY(skinny_plain(B, S, &spr, 1, nullptr, 1, sc, ldS, s));
-        else
-            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, S, H, htop_base + t * BH, H, d.w_attn + E, Q, nullptr, 0,
-                              nullptr, 0, 0, nullptr, nullptr, 1, sc, ldS, -1, s));
-        MMQG_TRY(attn_softmax_context_fwd(v, sc, ldS, at, ldS, cx, C, s));
+        // scores += h_top(t-1) * W_attn[:, E:]^T     (decoder.py:78,84,92: query = [emb | h_top]), softmax, contexts:
+        // ONE launch when the caller gave the fused kernel its workspace and the operands allow it (attention_fused.hip)
+        int fused_attn = 1;
+        if (d.attn_ws && !g_no_fuse())
+            fused_attn = attn_fused_fwd(v, sc, ldS, htop_base + t * BH, H, d.w_attn + E, Q, H, at, ldS, cx, C, d.attn_ws,
+                                        d.attn_ws_bytes, s);
+        if (fused_attn < 0) return fused_attn;
+        if (fused_attn != 0) {
+            const SkinnyPair spr{htop_base + t * BH, H, d.w_attn + E, Q, H, 0};
+            if (!g_no_fuse() && skinny_usable(&spr, 1))
+                MMQG_TRY(skinny_plain(B, S, &spr, 1, nullptr, 1, sc, ldS, s));
+            else
+                MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, S, H, htop_base + t * BH, H, d.w_attn + E, Q, nullptr, 0,
+                                  nullptr, 0, 0, nullptr, nullptr, 1, sc, ldS, -1, s));
+            MMQG_TRY(attn_softmax_context_fwd(v, sc, ldS, at, ldS, cx, C, s));
+        }
         for (int l = 0; l < L; ++l) {
             float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
             float* cs_l = d.cs + (int64_t)l * (T + 1) * BH;

@@ -310,6 +310,14 @@ class BatchedTrainer:
             if l > 0:
                 dd.w_ihT[l] = w["wihT_d"][l].data_ptr()
         dd.w_ih0cT, dd.w_attn_hT = w["wih0cT"].data_ptr(), w["wattn_hT"].data_ptr()
+        # score product + softmax + contexts of a step as ONE launch (csrc/attention_fused.hip): opt-in.  Measured at
+        # config 2 (round 3): 19.2 us per launch in isolation against 15.7 + 11.1 us for the two launches it replaces,
+        # but 30.5 us inside the step, where every token's 54 MB value stream has flushed the score matrix from the L2s
+        # and 64 questions re-read it — decoder forward 1.24 ms against 1.17 ms
+        n = int(_lib.load().mmqg_attn_fused_ws_bytes(C.byref(dd.values), H)) if os.environ.get("MMQG_ATTN_FUSE", "0") == "1" else 0
+        if n > 0:
+            w["attn_ws"] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)
+            dd.attn_ws, dd.attn_ws_bytes = w["attn_ws"].data_ptr(), n
         self.d_dec, self.g_dec = dd, gd
 
     def _persist_ws(self, d, key):

@@ -215,6 +215,61 @@ def test_attention_forward_backward(mm, shape, mask_mode):
         close(a.grad, b.grad.float(), what=name)
 
 
+@pytest.mark.parametrize("shape", [(3, 9, 5, 16, 8, 16, 32), (64, 283, 101, 512, 128, 512, 512), (5, 33, 7, 132, 12, 36, 100),
+                                   (32, 283, 101, 512, 128, 512, 512), (6, 283, 101, 1024, 128, 1024, 1024),
+                                   (2, 700, 130, 64, 32, 128, 64)])
+@pytest.mark.parametrize("mask_mode,zero_past_len", [(0, 0), (1, 0), (0, 1)])
+def test_fused_score_product_softmax_context_in_one_launch(mm, shape, mask_mode, zero_past_len):
+    """mmqg_attn_scores_softmax_context_fwd (csrc/attention_fused.hip): scores = pre + h W^T, three softmaxes, three
+    contexts in ONE launch — row-range parts with local softmaxes merged by the last arriver of each (question,
+    modality) — against the float64 oracle; launched twice on the same workspace (the tickets must be left zero), with
+    the no-op and the intended masks and with the zero-padding skip."""
+    _lib, ops = mm
+    lib = _lib.load()
+    B, Lt, Lav, H, Da, Dv, Hq = shape
+    g = torch.Generator().manual_seed(sum(shape) + 7 * mask_mode + zero_past_len)
+    pre, text, audio, video, text_len, av_len = _attn_case(g, B, Lt, Lav, H, Da, Dv)
+    if zero_past_len:
+        text = text * (torch.arange(Lt).view(1, -1, 1) < text_len.view(-1, 1, 1))
+        audio = audio * (torch.arange(Lav).view(1, -1, 1) < av_len.view(-1, 1, 1))
+        video = video * (torch.arange(Lav).view(1, -1, 1) < av_len.view(-1, 1, 1))
+    S, Cw = Lt + 2 * Lav, H + Da + Dv
+    E = 20                                               # the score matrix is [S][E + Hq]; the kernel gets its recurrent half
+    Wfull = torch.randn(S, E + Hq, generator=g) * Hq ** -0.5
+    h = torch.randn(B, Hq, generator=g)
+    scores = pre.double() + h.double() @ Wfull[:, E:].double().t()
+    attn_w, ctx_w = _attn_oracle(scores, text.double(), audio.double(), video.double(), text_len, av_len, mask_mode)
+    fused = torch.cat((text.reshape(B, -1), audio.reshape(B, -1), video.reshape(B, -1)), dim=1).cuda()
+    v = _lib.AttnValues()
+    v.B, v.Lt, v.Lav, v.H, v.Da, v.Dv = B, Lt, Lav, H, Da, Dv
+    v.text, v.audio, v.video = fused.data_ptr(), fused.data_ptr() + 4 * Lt * H, fused.data_ptr() + 4 * (Lt * H + Lav * Da)
+    v.text_stride_b = v.audio_stride_b = v.video_stride_b = fused.shape[1]
+    tl, al = dev(text_len), dev(av_len)
+    v.text_len, v.av_len, v.mask_mode, v.zero_past_len = tl.data_ptr(), al.data_ptr(), mask_mode, zero_past_len
+    n = int(lib.mmqg_attn_fused_ws_bytes(C.byref(v), Hq))
+    assert n > 0, "the fused kernel must take these (16-byte aligned) extents"
+    ws = torch.zeros((n + 3) // 4, device="cuda")
+    ldS = (S + 3) // 4 * 4
+    pre_d = torch.zeros(B, ldS, device="cuda")
+    pre_d[:, :S] = pre.cuda()
+    Wd, hd = Wfull.cuda(), h.cuda()
+    for rep in range(2):
+        attn = torch.full((B, ldS), 7.0, device="cuda")
+        ctx = torch.full((B, Cw), 7.0, device="cuda")
+        rc = lib.mmqg_attn_scores_softmax_context_fwd(C.byref(v), pre_d.data_ptr(), ldS, hd.data_ptr(), Hq,
+                                                      Wd.data_ptr() + 4 * E, E + Hq, Hq, attn.data_ptr(), ldS, ctx.data_ptr(), Cw,
+                                                      ws.data_ptr(), n, ops._stream())
+        assert rc == 0, _lib.load().mmqg_last_error()
+        close(attn[:, :S], attn_w.float(), what=f"fused attention weights (launch {rep})")
+        close(ctx, ctx_w.float(), what=f"fused contexts (launch {rep})")
+        assert bool((attn[:, S:] == 7.0).all()), "wrote past the score row"
+    assert bool((ws.view(torch.int32)[-(B * 3):] == 0).all()), "tickets must be zero after a launch"
+    # operands the kernel does not take (query rows not 16-byte aligned) are declined, not mangled
+    rc = lib.mmqg_attn_scores_softmax_context_fwd(C.byref(v), pre_d.data_ptr(), ldS, hd.data_ptr(), Hq, Wd.data_ptr() + 4 * (E + 1),
+                                                  E + Hq, Hq, attn.data_ptr(), ldS, ctx.data_ptr(), Cw, ws.data_ptr(), n, ops._stream())
+    assert rc == 1
+
+
 def test_attention_accepts_the_fused_value_layout(mm):
     """One allocation per question holding text | audio | video rows (the layout the batched
     trainer uses) must give the same result as three separate tensors."""

@@ -43,6 +43,7 @@ def run(B, Lt, Lav, H=512, Da=128, Dv=512, iters=300, T=20):
 
 print("chunk", os.environ.get("MMQG_ATTN_CHUNK", "128"))
 run(64, 283, 101)
+run(32, 283, 101)
 run(64, 32, 8)
 run(128, 283, 101, H=1024, Dv=1024)
 run(512, 283, 101)
