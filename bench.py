@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
     ap.add_argument("--kernel-iters", type=int, default=200, help="launches per kernel-duration measurement")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the self-launched ranks may take in all")
     ap.add_argument("--skip-zero-rows", action="store_true",
                     help="attention kernels skip the zero-padded value rows (identical results; NOT the default: the "
                          "roofline is defined on streaming the padded extents)")
@@ -85,16 +86,43 @@ def self_launch_needed(gpus: int, env) -> bool:
 def self_launch(a, argv) -> int:
     """Start the N ranks as a child process tree.  Nothing in this process has touched the GPU yet
     (``import torch`` and ``device_count`` do not), and this process never execs: it waits for the
-    launcher and hands its exit code on."""
-    have = torch.cuda.device_count()
+    launcher and hands its exit code on.  Fails fast with a one-line reason and a non-zero exit code when the node
+    has fewer devices than ranks, when any rank dies (the launcher then tears the others down) or when the ranks do
+    not finish within --launch-timeout seconds (a rank stuck in rendezvous or in a collective)."""
+    have = int(os.environ.get("MMQG_BENCH_FAKE_DEVICES", "0")) or torch.cuda.device_count()
     if have < a.gpus:
-        print(f"bench.py: --gpus {a.gpus} but this node shows {have} device(s)", file=sys.stderr)
+        print(f"bench.py: FAILED: --gpus {a.gpus} but this node shows {have} device(s)", file=sys.stderr)
         return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = launcher_command(a.gpus, argv, free_port())
-    return subprocess.run(cmd, env=env).returncode
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        rc = proc.wait(timeout=a.launch_timeout)
+    except subprocess.TimeoutExpired:
+        import signal
+        # the launcher puts every rank into a session of its own: collect the whole tree (exact PIDs) before killing
+        victims = [proc.pid]
+        try:
+            import psutil
+            victims += [c.pid for c in psutil.Process(proc.pid).children(recursive=True)]
+        except Exception:
+            pass
+        for pid in reversed(victims):
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        proc.wait()
+        print(f"bench.py: FAILED: the {a.gpus} ranks did not finish within {a.launch_timeout:.0f} s (a rank stuck in rendezvous "
+              f"or in a collective); the launcher and its ranks were killed", file=sys.stderr)
+        return 3
+    if rc != 0:
+        print(f"bench.py: FAILED: the launcher exited with code {rc}: at least one of the {a.gpus} ranks died (its traceback is "
+              f"above); no result line was printed", file=sys.stderr)
+        return rc if 0 < rc < 256 else 1
+    return 0
 
 
 # --------------------------------------------------------------------------------- rooflines
@@ -143,6 +171,93 @@ def recorded_traffic(workload_key):
     return rec.get("hbm_bytes_per_launch"), f"{rec.get('kernel')} grid {rec.get('grid')}"
 
 
+def recorded_in_step(workload_key):
+    """In-step duration of the attention forward launch (profiles/attn_in_step.json, written by tools/attn_in_step.py
+    from a rocprofv3 kernel-trace of `bench.py --kernel-iters 0`): only a record taken on the attention.hip that is
+    loaded now counts."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "attn_in_step.json"))).get(workload_key)
+    except Exception:
+        return None
+    if not rec or rec.get("source_sha") != source_sha("multi-modal-qg_amd/csrc/attention.hip"):
+        return None
+    return rec
+
+
+def graph_time(fn, reps=10):
+    """Average GPU time of fn() captured into a hipGraph and replayed (what the step does), HIP events."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def loop_rooflines(tr, w):
+    """The four dependent time loops of the step (75% of its time), each replayed alone as a graph: time per token /
+    per wavefront diagonal, the arithmetic and the distinct operand bytes of that unit, and what fraction of the fp32
+    MFMA peak / of the HBM peak that is.  Neither bound is near: these loops are bound by the number of dependent
+    stages (launch boundaries or device-wide barriers) per unit."""
+    from mmqg_amd import _lib, ops
+    lib = _lib.load()
+    B, H, L, E = tr.B, tr.H, tr.L, tr.E
+    Tc, Td, S, Cw = tr.Tc, tr.Td, tr.S, tr.Cw
+    vals = 4 * (tr.Lt * H + tr.Lav * tr.Da + tr.Lav * tr.Dv)
+
+    def s():
+        return ops._stream()
+
+    def dec_fwd():
+        tr.d_dec.phase = 2
+        _lib.check(lib.mmqg_decoder_seq_fwd(C.byref(tr.d_dec), s()))
+        tr.d_dec.phase = 0
+
+    def dec_bwd():
+        tr.g_dec.phase = 1
+        _lib.check(lib.mmqg_decoder_seq_bwd(C.byref(tr.d_dec), C.byref(tr.g_dec), s()))
+        tr.g_dec.phase = 0
+
+    def text_fwd():
+        _lib.check(lib.mmqg_lstm_seq_fwd(C.byref(tr.d_text), s()))
+
+    def text_bwd():
+        tr.g_text.phase = 1
+        _lib.check(lib.mmqg_lstm_seq_bwd(C.byref(tr.d_text), C.byref(tr.g_text), s()))
+        tr.g_text.phase = 0
+
+    lstm_w = 4 * (4 * H * (Cw + H) + (L - 1) * 4 * H * 2 * H)            # decoder recurrent weights, bytes
+    dec_flop = 2.0 * B * (S * H + 4 * H * (Cw + H) + (L - 1) * 4 * H * 2 * H) + 2.0 * B * vals / 4
+    dec_bytes = lstm_w + 4 * S * H + B * vals
+    text_flop = 2.0 * B * (4 * H * H + (L - 1) * 4 * H * 2 * H)           # per diagonal, all layers (input product hoisted)
+    out = {}
+    for name, fn, units, unit, flop, nbytes, stages in (
+            ("decoder_fwd", dec_fwd, Td, "token", dec_flop, dec_bytes, "5 dependent launches per token"),
+            ("decoder_bwd", dec_bwd, Td, "token", 2 * dec_flop, dec_bytes + B * vals, "5 dependent launches per token"),
+            ("text_encoder_fwd", text_fwd, Tc + L - 1, "diagonal", text_flop, 4 * B * 2 * H * L,
+             "persistent: 1 device-wide barrier per diagonal, weights resident in LDS"),
+            ("text_encoder_bwd", text_bwd, Tc + L - 1, "diagonal", text_flop, 4 * B * 8 * H * L,
+             "persistent: 2 device-wide barriers per diagonal, weights resident in LDS")):
+        dt = graph_time(fn)
+        per = dt / units
+        out[name] = {"us_per_" + unit: round(per * 1e6, 2), "ms": round(dt * 1e3, 4), "gflop_per_" + unit: round(flop / 1e9, 3),
+                     "achieved_tflops": round(flop / per / 1e12, 2),
+                     "frac_of_fp32_mfma_peak": round(flop / per / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                     "distinct_operand_bytes_per_" + unit: int(nbytes), "achieved_gbs": round(nbytes / per / 1e9, 1),
+                     "frac_of_hbm_peak": round(nbytes / per / 1e9 / HBM_PEAK_GBS, 4), "bound": "latency: " + stages}
+    out["persistent_launches"] = {"forward": int(lib.mmqg_persist_launch_count()), "backward": int(lib.mmqg_persist_bwd_launch_count())}
+    return out
+
+
 def kernel_rooflines(tr, w, iters):
     from mmqg_amd import _lib, ops
     lib, s = _lib.load(), ops._stream()
@@ -185,10 +300,23 @@ def kernel_rooflines(tr, w, iters):
                                                      ldS, cx[t].data_ptr(), Cw, s))
     dtc = time_launches(attn_cold, max(iters, 4 * n_rot))
     del rot
+    # what the step itself runs: the launches between the score product and the layer-0 cell of every decode step (cold
+    # L2: the layer-step kernels in between stream the LSTM weights through it), from the rocprofv3 kernel-trace of
+    # `bench.py --kernel-iters 0` recorded under profiles/ (hash-checked against the loaded attention.hip)
+    rec = recorded_in_step(key)
+    dt_b2b = dt
+    basis = "back-to-back launches on the step's own buffers, HIP events (no in-step record for this attention.hip)"
+    if rec:
+        dt = rec["us_per_launch"] * 1e-6
+        basis = ("in-step launches: rocprofv3 kernel-trace of `bench.py --kernel-iters 0`, %d launches, recorded in "
+                 "profiles/attn_in_step.json" % rec["launches"])
     roof = {"kernel": "attn_softmax_context_fwd_kernel<64>", "bound": "hbm", "achieved": round(nbytes / dt / 1e9, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4), "frac_basis": basis,
             "traffic": traffic, "traffic_source": note, "bytes_per_launch": nbytes, "us_per_launch": round(dt * 1e6, 2),
-            "served_from": "in situ: the step's own value tensor, re-read every decode step (Infinity Cache resident "
+            "us_per_launch_back_to_back": round(dt_b2b * 1e6, 2),
+            "achieved_back_to_back": round(nbytes / dt_b2b / 1e9, 1),
+            "frac_back_to_back": round(nbytes / dt_b2b / 1e9 / HBM_PEAK_GBS, 4),
+            "served_from": "the step's own value tensor, re-read every decode step (Infinity Cache resident "
                            "when it is < 256 MiB)",
             "achieved_beyond_mall": round(nbytes / dtc / 1e9, 1),
             "frac_beyond_mall": round(nbytes / dtc / 1e9 / HBM_PEAK_GBS, 4),
@@ -226,6 +354,27 @@ def kernel_rooflines(tr, w, iters):
                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
     mfma.update({"traffic": None, "flops_per_launch": flops, "us_per_launch": round(dtp * 1e6, 2)})
     return roof, mfma
+
+
+def allreduce_times(tr, iters=5):
+    """Per-bucket all-reduce time of the gradient exchange (every rank calls this; RCCL over xGMI for N > 1): each
+    bucket of flat_g reduced alone, HIP events on the current stream, average of a few repetitions after one warm-up.
+    Not part of the timed step (there the first two buckets travel beside the text encoder's backward)."""
+    import torch.distributed as dist
+    out = {}
+    for name, (lo, hi) in tr.reducer.buckets.items():
+        buf = tr.flat_g[lo:hi]
+        dist.all_reduce(buf, group=tr.pg)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            dist.all_reduce(buf, group=tr.pg)
+        e1.record()
+        e1.synchronize()
+        out[name] = {"ms": round(e0.elapsed_time(e1) / iters, 4), "bytes": int((hi - lo) * 4)}
+    tr.flat_g.zero_()
+    return out
 
 
 # ------------------------------------------------------------------------------ CPU baseline
@@ -310,7 +459,11 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(f"bench.py: FAILED: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("MMQG_BENCH_TEST_RANK_FAIL") == str(rank):      # test hook: this rank dies before it touches the GPU
+        raise SystemExit(17)
+    if "MMQG_BENCH_TEST_RANK_HANG" in os.environ:                      # test hook: ranks that never finish
+        time.sleep(3600)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_pg = world > 1 or (os.environ.get("MMQG_FORCE_DP") == "1" and "RANK" in os.environ)
@@ -320,7 +473,8 @@ def main(argv=None):
         torch.distributed.init_process_group("nccl", device_id=dev)
         backend = f"{torch.distributed.get_backend()} (RCCL)"
         if torch.distributed.get_world_size() != world:
-            raise SystemExit("process group size does not match WORLD_SIZE")
+            raise SystemExit(f"bench.py: FAILED: the process group has {torch.distributed.get_world_size()} ranks, "
+                             f"WORLD_SIZE says {world}")
     w = WORKLOADS[a.workload]
     B = a.batch or w.batch
     vid, text, dec = build_models(w, dev, seed=0)          # same seed on every rank: identical replicas
@@ -365,9 +519,13 @@ def main(argv=None):
                       "world_size": torch.distributed.get_world_size() if use_pg else 1,
                       "collective_backend": backend},
            "final_loss": round(loss_val, 4)}
+    if use_pg:
+        out["config"]["allreduce_ms"] = allreduce_times(tr)
     if rank == 0:
-        roof, mfma = kernel_rooflines(tr, w, a.kernel_iters)
-        out["roofline"], out["roofline_mfma"] = roof, mfma
+        if a.kernel_iters > 0:
+            roof, mfma = kernel_rooflines(tr, w, a.kernel_iters)
+            out["roofline"], out["roofline_mfma"] = roof, mfma
+            out["roofline_loops"] = loop_rooflines(tr, w)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, a.cpu_seconds)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

@@ -223,3 +223,25 @@ def test_bench_launches_itself_for_more_than_one_gpu(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 2 and "--gpus 64" in r.stderr and "device(s)" in r.stderr
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies_or_hangs():
+    """`bench.py --gpus N` must not hang or print a half result when a rank is lost: one rank dies before
+    it touches the GPU (test hook) -> the launcher tears the others down, the parent prints ONE `FAILED` line naming the
+    reason, no JSON line, non-zero exit code; a launch that does not finish within --launch-timeout is killed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MMQG_BENCH_FAKE_DEVICES="2", MMQG_BENCH_TEST_RANK_FAIL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    failed = [ln for ln in r.stderr.splitlines() if ln.startswith("bench.py: FAILED")]
+    assert len(failed) == 1 and "ranks died" in failed[0], r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no result line may be printed"
+    # a launch that exceeds its time limit is killed with its whole process group
+    env.pop("MMQG_BENCH_TEST_RANK_FAIL")
+    env["MMQG_BENCH_TEST_RANK_HANG"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--launch-timeout", "20"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3
+    failed = [ln for ln in r.stderr.splitlines() if ln.startswith("bench.py: FAILED")]
+    assert len(failed) == 1 and "did not finish within 20 s" in failed[0], r.stderr[-1500:]
