@@ -287,6 +287,14 @@ int mmqg_persist_set_test_fault(int extra_workgroups, uint32_t max_spins);
  * separate instantiation of the kernel: the product kernel carries no stamps. */
 int mmqg_persist_set_trace(uint64_t* buf, int64_t words);
 int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_stream stream);
+/* The backward TIME LOOPS (phase 1 of mmqg_lstm_seq_bwd) of two independent stacks in one call: (d, g) as above and a
+ * second, single-layer stack (d2, g2) of the same B and H — the frame LSTM of VideoConvLstmEncoder (encoder.py:54,69)
+ * beside the text encoder's (encoder.py:91), whose gradients both become available when the decoder's backward loop
+ * ends (train.py:177).  When g->persist_ws is given and the persistent kernel takes the pair, both loops are ONE
+ * launch (the second stack's T2 steps ride on the first T2 anti-diagonals); otherwise each loop runs on its own.
+ * Phase 2 (weight gradients, dx) of each stack is the caller's next call.  g->phase / g2->phase are ignored. */
+int mmqg_lstm_seq_bwd_pair(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, const mmqg_lstm_seq* d2,
+                           const mmqg_lstm_seq_grad* g2, mmqg_stream stream);
 /* bytes of mmqg_lstm_seq_grad.persist_ws for this shape; 0 = shape not taken (B > 64, H not a multiple of 64 or
  * below 128, weights beyond the chip's LDS, ...): the backward then runs one launch per anti-diagonal */
 int64_t mmqg_lstm_seq_bwd_persist_ws_bytes(int T, int B, int L, int H);

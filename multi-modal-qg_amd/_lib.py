@@ -184,6 +184,7 @@ SIGNATURES = {
     "mmqg_persist_set_test_fault": [C.c_int, C.c_uint32],
     "mmqg_persist_set_trace": [c_f, c_i64],
     "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
+    "mmqg_lstm_seq_bwd_pair": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
     "mmqg_decoder_decode_run": [C.POINTER(DecoderDecode), c_f],
     "mmqg_sample_gumbel": [c_f, c_i, c_i, c_i, c_u64, c_u64, c_f, c_f],
     "mmqg_frame_cnn_fwd": [C.POINTER(FrameCnn), c_f],

@@ -20,6 +20,8 @@ const char* get_error() { return g_err; }
 
 int lstm_seq_fwd(const mmqg_lstm_seq& d, hipStream_t s);
 int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s);
+int lstm_seq_bwd_pair(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, const mmqg_lstm_seq& d2, const mmqg_lstm_seq_grad& g2,
+                      hipStream_t s);
 int64_t lstm_persist_ws_bytes(int T, int B, int L, int H);
 int persist_launch_count();
 void persist_set_trace(unsigned long long* buf, int64_t words);
@@ -199,6 +201,12 @@ int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_
     MMQG_REQUIRE(d && g, "mmqg_lstm_seq_bwd: null descriptor");
     MMQG_TRY(persist_check_healthy("mmqg_lstm_seq_bwd"));
     return lstm_seq_bwd(*d, *g, S(stream));
+}
+int mmqg_lstm_seq_bwd_pair(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, const mmqg_lstm_seq* d2,
+                           const mmqg_lstm_seq_grad* g2, mmqg_stream stream) {
+    MMQG_REQUIRE(d && g && d2 && g2, "mmqg_lstm_seq_bwd_pair: null descriptor");
+    MMQG_TRY(persist_check_healthy("mmqg_lstm_seq_bwd_pair"));
+    return lstm_seq_bwd_pair(*d, *g, *d2, *g2, S(stream));
 }
 int mmqg_frame_cnn_fwd(const mmqg_frame_cnn* d, mmqg_stream stream) {
     MMQG_REQUIRE(d, "mmqg_frame_cnn_fwd: null descriptor");

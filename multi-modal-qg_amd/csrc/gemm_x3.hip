@@ -577,7 +577,9 @@ bool gemm_x3_enabled() {
 // worth taking: big enough that the tile grid (with k slices) fills the chip and the arithmetic dominates; short-K
 // products (the embedding-width hoists, K = 300) run as fast on the fp32 MFMA kernels (tools/x3_check.py)
 bool gemm_x3_wants(int M, int N, int K) {
-    return gemm_x3_enabled() && M >= 96 && N >= 96 && K >= 512 && (double)M * N * K >= 2.5e8;
+    // MMQG_X3_MIN_K: shortest K the split-bf16 kernel takes (A/B switch; the hoisted K = 300 products of the step)
+    static const int min_k = [] { const char* e = getenv("MMQG_X3_MIN_K"); return e ? atoi(e) : 512; }();
+    return gemm_x3_enabled() && M >= 96 && N >= 96 && K >= min_k && (double)M * N * K >= 2.5e8;
 }
 
 // Vocabulary projection logits = h W^T + bias with the loss's row statistics per 128-column tile (same layout as

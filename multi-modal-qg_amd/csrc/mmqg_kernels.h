@@ -96,6 +96,8 @@ int skinny_plain_multi(const SkinnyPlainJob* jobs, int njobs, hipStream_t s);
 // one cell-backward layer-step plus up to 2 independent plain products in ONE launch
 int skinny_cell_bwd_plus(const SkinnyBwdJob& cell, const SkinnyPlainJob* extra, int nextra, hipStream_t s);
 int skinny_cell_fwd_multi(const SkinnyFwdJob* jobs, int njobs, hipStream_t s);
+// one cell-forward layer-step plus up to 2 independent plain products in ONE launch
+int skinny_cell_fwd_plus(const SkinnyFwdJob& cell, const SkinnyPlainJob* extra, int nextra, hipStream_t s);
 int skinny_cell_bwd_multi(const SkinnyBwdJob* jobs, int njobs, hipStream_t s);
 int transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t s);
 int transpose_f32_batch(const mmqg_transpose_job* jobs, int n, hipStream_t s);
@@ -151,7 +153,8 @@ int persist_launch_count();
 // persist_bwd.hip: the backward time loop of an LSTM stack as one persistent launch
 bool lstm_persist_bwd_shape_ok(int T, int B, int L, int H);
 int64_t lstm_persist_bwd_ws_bytes(int T, int B, int L, int H);
-int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s);
+int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, const mmqg_lstm_seq* d2,
+                            const mmqg_lstm_seq_grad* g2, hipStream_t s);
 int persist_bwd_launch_count();
 void persist_bwd_set_trace(unsigned long long* buf, int64_t words);
 // persist_rt.hip: who may launch a persistent kernel, and how a failed one reaches the host

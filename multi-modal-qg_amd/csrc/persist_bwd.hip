@@ -48,15 +48,27 @@ constexpr int kRing = 4;               // operand chunks (1 KB per wave) in flig
 constexpr int kLdsBudget = 160 * 1024 - 1024;
 constexpr int kMaxSlices = 8;          // partial tiles a phase-B wave sums per product
 
+constexpr int kMaxCL = kMaxL + 1;      // cell layers of one launch: the stack's L layers + one layer of a second stack
+
+// one cell layer of the launch: layer l of the stack, or the single layer of the second ("aux") stack that rides
+// along (the frame LSTM's backward beside the text encoder's: its T_aux steps sit on the first T_aux diagonals)
+struct CellLayer {
+    const float* w_hh; const float* w_hhT;      // [4H][H] as torch keeps it / optional k-major copy [H][4H] (faster prologue)
+    const float* gates; const float* cs;        // saved activations of this layer: [T][B][4H], [T+1][B][H]
+    const int32_t* lens;
+    const float* dy; int64_t dy_stride_t, dy_stride_b;     // gradient of the layer's outputs (top layers only), nullable
+    const float* dhT; const float* dcT;         // gradient of the final state [B][H], nullable
+    float* dgates;                              // out [T][B][4H]
+    float* dh_out; float* dc_out;               // out [B][H]: what is left of dh / dc after step 0
+    int T, doff;                                // steps; diagonal on which its step T - 1 sits
+};
+
 struct BwdArgs {
-    int T, B, L, H, G, Cper;           // Cper: k-chunks (16 k x 64 columns) per workgroup, a multiple of kRing
-    const float* w_hh[kMaxL]; const float* w_ih[kMaxL];       // [4H][H] as torch keeps them
-    const float* gates; const float* cs; const int32_t* lens;
-    const float* dy; int64_t dy_stride_t, dy_stride_b;
-    const float* dhT; const float* dcT;
-    float* dgates; float* dh_out; float* dc_out;
-    float drop_p; int drop; uint64_t seed, stream_base; const int32_t* seed_off;
-    float* dgx;            // [L][2][4H/4][64][4]  dG_l(t), slot = t & 1; directly followed by
+    int B, L, NL, H, G, Cper, ndiag;   // L layers of the stack, NL cell layers in all; Cper: k-chunks per workgroup
+    CellLayer lay[kMaxCL];
+    const float* w_ih[kMaxL]; const float* w_ihT[kMaxL];      // [4H][H] / [H][4H], layers >= 1 of the stack
+    float drop_p; int drop; uint64_t seed, stream_base; const int32_t* seed_off; int T0;   // dropout streams: stream_base + l * T0 + t
+    float* dgx;            // [NL][2][4H/4][64][4]  dG_l(t), slot = t & 1; directly followed by
     float* part;           // [G][2][4][64][16]    partial tiles: (workgroup, segment, column tile, row, 16 columns)
     gb::XBar* bar;
     float* poison; unsigned* sticky_fail; unsigned* host_fail; unsigned expect_wg, max_spins;
@@ -72,6 +84,8 @@ __device__ __forceinline__ P pick(P const (&arr)[kMaxL], int l) {
     static_assert(kMaxL == 3, "pick() lists three layers");
     return l == 0 ? arr[0] : (l == 1 ? arr[1] : arr[2]);
 }
+// field of cell layer l without indexing the by-value argument array at run time (that would make a scratch copy)
+#define LSEL(field, l) ((l) == 0 ? a.lay[0].field : ((l) == 1 ? a.lay[1].field : ((l) == 2 ? a.lay[2].field : a.lay[3].field)))
 
 // dropout keep-scales of the four elements idx .. idx+3 (idx a multiple of 4): the one Philox block dropout_scale()
 // would compute for each of them
@@ -93,12 +107,13 @@ __device__ __forceinline__ f32x4 tanh4(const f32x4& v) { return f32x4{tanhf(v.x)
 struct Seg {             // a workgroup's share of one unit
     int n;               // k-chunks (0 = none), a multiple of kRing
     int lo;              // first chunk inside the unit
-    int prod, ng;        // product (0..L-1: W_hh of layer prod; L..2L-2: W_ih of layer prod-L+1) and column group
+    int prod, ng;        // product (0..NL-1: W_hh of cell layer prod; NL..NL+L-2: W_ih of layer prod-NL+1) and column group
     int wbase;           // LDS float4 index of its first weight fragment
+    int lc, hh, lsrc, Tc, doff;   // cell layer the product feeds, W_hh or W_ih, layer whose dG it multiplies, that cell's T / doff
 };
 
 #define MMQG_BSTAMP(slot)                                                                              \
-    if (TRACE && tid == 0) a.trace[((size_t)blockIdx.x * (T + L - 1) + s) * 6 + (slot)] = wall_clock64();
+    if (TRACE && tid == 0) a.trace[((size_t)blockIdx.x * a.ndiag + s) * 6 + (slot)] = wall_clock64();
 
 // 16 k of one chunk for the wave's two column tiles (two independent accumulator chains)
 __device__ __forceinline__ void mfma_chunk2(f32x4& acc0, f32x4& acc1, const f32x4& w0, const f32x4& w1, const f32x4& x) {
@@ -144,10 +159,10 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = a.T, B = a.B, L = a.L, H = a.H;
+    const int B = a.B, L = a.L, NL = a.NL, H = a.H;
     const int CPU = H / 4;                       // k-chunks per unit (K = 4H, 16 k per chunk)
     const int NG = H / kColsPerUnit;             // column groups per product
-    const int nunits = (2 * L - 1) * NG;
+    const int nunits = (NL + L - 1) * NG;
     const int total = nunits * CPU;
     const int slot_f = kRows * 4 * H;            // floats per (layer, slot) of the dG exchange buffer
 
@@ -160,23 +175,38 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
         sg[0].n = min(CPU - lo0, count); sg[0].lo = lo0; sg[0].prod = u0 / NG; sg[0].ng = u0 - sg[0].prod * NG; sg[0].wbase = 0;
         const int u1 = u0 + 1;
         sg[1].n = count - sg[0].n; sg[1].lo = 0; sg[1].prod = u1 / NG; sg[1].ng = u1 - sg[1].prod * NG; sg[1].wbase = sg[0].n * 256;
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            Seg& g = sg[si];
+            g.hh = g.prod < NL ? 1 : 0;
+            g.lc = g.hh ? g.prod : g.prod - NL;                      // W_ih of layer lc + 1 feeds cell layer lc
+            g.lsrc = g.hh ? g.lc : g.lc + 1;
+            g.Tc = LSEL(T, g.lc); g.doff = LSEL(doff, g.lc);
+        }
     }
     // ---- weights -> LDS in fragment order: chunk c, column tile ct, lane (i = lane & 15: output column, kq = lane >> 4):
-    // W[k = 16 c + 4 kq + {0..3}][n = 64 ng + 16 ct + i] of the product's matrix ([4H][H], so the four k are H apart)
+    // W[k = 16 c + 4 kq + {0..3}][n = 64 ng + 16 ct + i] of the product's matrix.  From the k-major copy [H][4H] when the
+    // caller keeps one (one 16-byte load), else from the [4H][H] original (four loads H apart).
 #pragma unroll
     for (int si = 0; si < 2; ++si) {
         const Seg& g = sg[si];
-        const float* W = g.prod < L ? pick(a.w_hh, g.prod) : pick(a.w_ih, g.prod - L + 1);
+        const float* W = g.hh ? LSEL(w_hh, g.lc) : pick(a.w_ih, g.lsrc);
+        const float* WT = g.hh ? LSEL(w_hhT, g.lc) : pick(a.w_ihT, g.lsrc);
         const int nf = g.n * 256;
         for (int idx = tid; idx < nf; idx += kThreads) {
             const int c = idx >> 8, ct = (idx >> 6) & 3, l = idx & 63, i = l & 15, kq = l >> 4;
-            const float* src = W + (int64_t)(16 * (g.lo + c) + 4 * kq) * H + kColsPerUnit * g.ng + 16 * ct + i;
-            lds[g.wbase + idx] = f32x4{src[0], src[H], src[2 * H], src[3 * H]};
+            const int k = 16 * (g.lo + c) + 4 * kq, n = kColsPerUnit * g.ng + 16 * ct + i;
+            if (WT) {
+                lds[g.wbase + idx] = *reinterpret_cast<const f32x4*>(WT + (int64_t)n * 4 * H + k);
+            } else {
+                const float* src = W + (int64_t)k * H + n;
+                lds[g.wbase + idx] = f32x4{src[0], src[H], src[2 * H], src[3 * H]};
+            }
         }
     }
 
     // one descriptor over the dG exchange buffer and the partial tiles behind it (sc1 loads / stores: aux = 16)
-    const int part_base = L * 2 * slot_f * 4;                         // byte offset of the partial tiles
+    const int part_base = NL * 2 * slot_f * 4;                        // byte offset of the partial tiles
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.dgx, 0, part_base + a.G * 2 * 4 * kRows * 16 * 4, 0x00020000);
 
     // ---- phase-A role of this wave: row block rb, column tiles 2 ch and 2 ch + 1
@@ -185,28 +215,41 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
     const int xlane = (q * kRows + rb * 16 + j) * 16;                 // byte offset inside an operand chunk
     const int plane = ((rb * 16 + j) * 16 + 4 * q) * 4;               // byte offset inside a [64][16] partial column tile
 
-    // ---- phase-B role: wave-task tau = (layer, 16 hidden units, 16 rows); lane = (row r, unit quad cq)
-    const int ntask = L * (H / 16) * 4;
+    // ---- phase-B role: wave-task tau = (cell layer, 16 hidden units, 16 rows); lane = (row r, unit quad cq)
+    const int per_layer = (H / 16) * 4;
+    const int ntask = NL * per_layer;
     const int tau = blockIdx.x + a.G * wave;
     const bool has_task = tau < ntask;
-    const int tl = has_task ? tau / ((H / 16) * 4) : 0;               // layer
+    const int tl = has_task ? tau / per_layer : 0;                    // cell layer
     const int tct = has_task ? (tau >> 2) % (H / 16) : 0;             // 16-unit tile
     const int trb = tau & 3;                                          // row block
     const int br = trb * 16 + (lane >> 2), cq = lane & 3;
     const int u0 = tct * 16 + 4 * cq;                                 // first of this lane's 4 hidden units
     const bool bvalid = has_task && br < B;
-    int blen = T;
+    // this wave's layer, once (wave-uniform values)
+    const int Tl = LSEL(T, tl), doffl = LSEL(doff, tl);
+    const float* gates_l = LSEL(gates, tl);
+    const float* cs_l = LSEL(cs, tl);
+    const float* dy_l = LSEL(dy, tl);
+    const int64_t dy_st = LSEL(dy_stride_t, tl), dy_sb = LSEL(dy_stride_b, tl);
+    float* dgates_l = LSEL(dgates, tl);
+    const bool stack_layer = tl < L;                                  // (else: the second stack's layer)
+    const bool has_above = stack_layer && tl < L - 1;
+    int blen = Tl;
     f32x4 dhc = f32x4{0.f, 0.f, 0.f, 0.f}, dcc = dhc;                 // pass-through dh and dc of (tl, br, u0..u0+3)
     if (bvalid) {
-        if (a.lens) blen = a.lens[br];
-        if (a.dhT) dhc = *reinterpret_cast<const f32x4*>(a.dhT + ((int64_t)tl * B + br) * H + u0);
-        if (a.dcT) dcc = *reinterpret_cast<const f32x4*>(a.dcT + ((int64_t)tl * B + br) * H + u0);
+        const int32_t* lens = LSEL(lens, tl);
+        const float* dhT = LSEL(dhT, tl);
+        const float* dcT = LSEL(dcT, tl);
+        if (lens) blen = lens[br];
+        if (dhT) dhc = *reinterpret_cast<const f32x4*>(dhT + (int64_t)br * H + u0);
+        if (dcT) dcc = *reinterpret_cast<const f32x4*>(dcT + (int64_t)br * H + u0);
     }
     // where the partial tiles of this task's two products come from: unit -> workgroups [cA, cB], segment index
     const int tng = tct >> 2, tctl = tct & 3;
     int hhA, hhN, ihA, ihN, hh_first, ih_first;
     {
-        const int uh = tl * NG + tng, ui = (L + tl) * NG + tng;
+        const int uh = tl * NG + tng, ui = (NL + tl) * NG + tng;
         hhA = (uh * CPU) / a.Cper; hhN = ((uh + 1) * CPU - 1) / a.Cper - hhA + 1; hh_first = uh * CPU;
         ihA = (ui * CPU) / a.Cper; ihN = ((ui + 1) * CPU - 1) / a.Cper - ihA + 1; ih_first = ui * CPU;
     }
@@ -218,21 +261,21 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     const uint64_t seed = a.drop ? eff_seed(a.seed, a.seed_off) : 0;
-    for (int s = 0; ok && s < T + L - 1; ++s) {
+    for (int s = 0; ok && s < a.ndiag; ++s) {
         MMQG_BSTAMP(0)
         // ---- phase B operands that do not depend on the chain: requested now, used after the first barrier
-        const int tt = (T - 1) - (s - (L - 1 - tl));                  // time of this wave's cell on this diagonal
-        const bool con = has_task && tt >= 0 && tt < T;
+        const int tt = (Tl - 1) - (s - doffl);                        // time of this wave's cell on this diagonal
+        const bool con = has_task && tt >= 0 && tt < Tl;
         f32x4 gi, gf, gg, go, cprev, cnew, dy4;
         gi = gf = gg = go = cprev = cnew = dy4 = f32x4{0.f, 0.f, 0.f, 0.f};
         const bool cact = con && bvalid && tt < blen;
         if (cact) {
-            const float* gr = a.gates + (((int64_t)tl * T + tt) * B + br) * 4 * H + u0;
+            const float* gr = gates_l + ((int64_t)tt * B + br) * 4 * H + u0;
             gi = *reinterpret_cast<const f32x4*>(gr); gf = *reinterpret_cast<const f32x4*>(gr + H);
             gg = *reinterpret_cast<const f32x4*>(gr + 2 * H); go = *reinterpret_cast<const f32x4*>(gr + 3 * H);
-            const float* cr = a.cs + (((int64_t)tl * (T + 1) + tt) * B + br) * H + u0;
+            const float* cr = cs_l + ((int64_t)tt * B + br) * H + u0;
             cprev = *reinterpret_cast<const f32x4*>(cr); cnew = *reinterpret_cast<const f32x4*>(cr + (int64_t)B * H);
-            if (tl == L - 1 && a.dy) dy4 = *reinterpret_cast<const f32x4*>(a.dy + (int64_t)tt * a.dy_stride_t + (int64_t)br * a.dy_stride_b + u0);
+            if (dy_l) dy4 = *reinterpret_cast<const f32x4*>(dy_l + (int64_t)tt * dy_st + (int64_t)br * dy_sb + u0);
         }
 
         // ---- phase A: partial products of this workgroup's segments
@@ -241,13 +284,11 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
 #pragma unroll
         for (int si = 0; si < 2; ++si) {
             const Seg& g = sg[si];
-            const int lc = g.prod < L ? g.prod : g.prod - L;          // layer of the CELL this product feeds
-            const int tc = (T - 1) - (s - (L - 1 - lc));
+            const int tc = (g.Tc - 1) - (s - g.doff);
             // W_hh_l needs dG_l(t+1) (slot (t+1)&1 of layer l); W_ih_{l+1} needs dG_{l+1}(t) (slot t&1 of layer l+1)
-            const bool hh = g.prod < L;
-            son[si] = g.n > 0 && tc >= 0 && tc < T && (!hh || tc + 1 < T);
-            const int lsrc = hh ? lc : lc + 1, slot = hh ? ((tc + 1) & 1) : (tc & 1);
-            xoff[si] = ((lsrc * 2 + slot) * slot_f) * 4 + (4 * g.lo) * kRows * 16 + xlane;
+            son[si] = g.n > 0 && tc >= 0 && tc < g.Tc && (!g.hh || tc + 1 < g.Tc);
+            const int slot = g.hh ? ((tc + 1) & 1) : (tc & 1);
+            xoff[si] = ((g.lsrc * 2 + slot) * slot_f) * 4 + (4 * g.lo) * kRows * 16 + xlane;
         }
         constexpr int chunk_bytes = 4 * kRows * 16;
         if (son[0]) {
@@ -282,7 +323,7 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
         dgi = dgf = dgg = dgo = f32x4{0.f, 0.f, 0.f, 0.f};
         if (con) {
             f32x4 ph = f32x4{0.f, 0.f, 0.f, 0.f}, pi = ph;
-            if (tt + 1 < T) {
+            if (tt + 1 < Tl) {
                 f32x4 v[kMaxSlices];
 #pragma unroll
                 for (int i = 0; i < kMaxSlices; ++i) {
@@ -296,7 +337,7 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
                     ph.x += w * v[i].x; ph.y += w * v[i].y; ph.z += w * v[i].z; ph.w += w * v[i].w;
                 }
             }
-            if (tl < L - 1) {
+            if (has_above) {
                 f32x4 v[kMaxSlices];
 #pragma unroll
                 for (int i = 0; i < kMaxSlices; ++i) {
@@ -310,7 +351,7 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
                     pi.x += w * v[i].x; pi.y += w * v[i].y; pi.z += w * v[i].z; pi.w += w * v[i].w;
                 }
                 if (a.drop) {
-                    const f32x4 m = dropout_scale4(seed, a.stream_base + (uint64_t)tl * T + tt, (uint64_t)((int64_t)br * H + u0), a.drop_p);
+                    const f32x4 m = dropout_scale4(seed, a.stream_base + (uint64_t)tl * a.T0 + tt, (uint64_t)((int64_t)br * H + u0), a.drop_p);
                     pi.x *= m.x; pi.y *= m.y; pi.z *= m.z; pi.w *= m.w;
                 }
             }
@@ -343,7 +384,7 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
         MMQG_BSTAMP(4)
         // ---- the gate gradients for the hoisted weight-gradient products: after the arrival, off the critical path
         if (con && bvalid) {
-            float* dg = a.dgates + (((int64_t)tl * T + tt) * B + br) * 4 * H + u0;
+            float* dg = dgates_l + ((int64_t)tt * B + br) * 4 * H + u0;
             *reinterpret_cast<f32x4*>(dg) = dgi; *reinterpret_cast<f32x4*>(dg + H) = dgf;
             *reinterpret_cast<f32x4*>(dg + 2 * H) = dgg; *reinterpret_cast<f32x4*>(dg + 3 * H) = dgo;
         }
@@ -352,8 +393,10 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
     }
     // what is left of dh / dc after step 0: the gradient of the initial state still lacks dG_l(0) W_hh_l (host side)
     if (bvalid) {
-        *reinterpret_cast<f32x4*>(a.dh_out + ((int64_t)tl * B + br) * H + u0) = dhc;
-        *reinterpret_cast<f32x4*>(a.dc_out + ((int64_t)tl * B + br) * H + u0) = dcc;
+        float* dh_out = LSEL(dh_out, tl);
+        float* dc_out = LSEL(dc_out, tl);
+        if (dh_out) *reinterpret_cast<f32x4*>(dh_out + (int64_t)br * H + u0) = dhc;
+        if (dc_out) *reinterpret_cast<f32x4*>(dc_out + (int64_t)br * H + u0) = dcc;
     }
     if (!ok) {
         gb::report_failure(a.sticky_fail, a.host_fail);
@@ -365,19 +408,19 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
 inline int64_t align_up(int64_t v, int64_t al) { return (v + al - 1) / al * al; }
 
 struct WsLayout { int64_t bar, dgx, part, sticky, total; };
-WsLayout ws_layout(int L, int H, int G) {
+WsLayout ws_layout(int NL, int H, int G) {
     WsLayout w;
     w.bar = 0;
     w.dgx = align_up((int64_t)sizeof(gb::XBar), 256);
-    w.part = w.dgx + (int64_t)L * 2 * kRows * 4 * H * 4;
+    w.part = w.dgx + (int64_t)NL * 2 * kRows * 4 * H * 4;
     w.sticky = w.part + (int64_t)G * 2 * 4 * kRows * 16 * 4;
     w.total = w.sticky + 256;
     return w;
 }
 
 // k-chunks per workgroup for G workgroups (a multiple of kRing), 0 = the shape does not fit
-int chunks_per_wg(int L, int H, int G) {
-    const int total = (2 * L - 1) * (H / kColsPerUnit) * (H / 4);
+int chunks_per_wg(int nprod, int H, int G) {
+    const int total = nprod * (H / kColsPerUnit) * (H / 4);
     int per = ceil_div(total, G);
     per = std::max(per, ceil_div(H / 4, kMaxSlices - 1));      // narrow layers: fewer, longer slices (some CUs stay idle)
     per = ceil_div(per, kRing) * kRing;
@@ -406,32 +449,48 @@ bool lstm_persist_bwd_shape_ok(int T, int B, int L, int H) {
     }();
     if (off) return false;
     return T >= 2 && B >= 1 && B <= kRows && L >= 1 && L <= kMaxL && H >= 128 && H % kColsPerUnit == 0 &&
-           (H / 4) % kRing == 0 && L * (H / 16) * 4 <= kMaxWG * kWaves;
+           (H / 4) % kRing == 0 && (L + 1) * (H / 16) * 4 <= kMaxWG * kWaves;
 }
 
 int64_t lstm_persist_bwd_ws_bytes(int T, int B, int L, int H) {
     if (!lstm_persist_bwd_shape_ok(T, B, L, H)) return 0;
     persist_runtime_prepare();
     const int G = std::min(persist_device_cus(), kMaxWG);
-    // (a CPU-only caller sizing buffers gets the 256-workgroup layout)
-    return ws_layout(L, H, G >= 64 ? G : kMaxWG).total;
+    // room for one cell layer of a second stack riding along (mmqg_lstm_seq_bwd_pair); a CPU-only caller sizing
+    // buffers gets the 256-workgroup layout
+    return ws_layout(L + 1, H, G >= 64 ? G : kMaxWG).total;
 }
 
-// 0 = done, 1 = not eligible (the caller takes the launch-per-diagonal path), < 0 = error
-int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s) {
+static bool grads_aligned(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g) {
+    if (!aligned16(d.gates) || !aligned16(d.cs) || !aligned16(g.dgates) || !aligned16(g.dh) || !aligned16(g.dc)) return false;
+    if (g.dy && (!aligned16(g.dy) || g.dy_stride_t % 4 || g.dy_stride_b % 4)) return false;
+    if ((g.dhT && !aligned16(g.dhT)) || (g.dcT && !aligned16(g.dcT))) return false;
+    return true;
+}
+
+// 0 = done, 1 = not eligible (the caller takes the launch-per-diagonal path), < 0 = error.
+// d2 / g2 (nullable): a second, single-layer stack of the same B and H whose backward time loop rides along in the same
+// launch (its T2 steps on the first T2 diagonals).
+int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, const mmqg_lstm_seq* d2,
+                            const mmqg_lstm_seq_grad* g2, hipStream_t s) {
     if (!g.persist_ws || !lstm_persist_bwd_shape_ok(d.T, d.B, d.L, d.H)) return 1;
     const int T = d.T, B = d.B, H = d.H, L = d.L;
+    const bool aux = d2 && g2;
+    if (aux && (d2->L != 1 || d2->H != H || d2->B != B || d2->T < 1 || !d2->w_hh[0] || !g2->dgates || !g2->dh || !g2->dc ||
+                !grads_aligned(*d2, *g2)))
+        return 1;
+    const int NL = L + (aux ? 1 : 0);
     const int G = std::min(persist_device_cus(), kMaxWG);
     if (G < 64) return 1;
-    const int per = chunks_per_wg(L, H, G);
+    const int per = chunks_per_wg(NL + L - 1, H, G);
     if (per == 0) return 1;
-    const WsLayout wl = ws_layout(L, H, G);
+    const WsLayout wl = ws_layout(NL, H, G);
     if (g.persist_ws_bytes < wl.total || !aligned16(g.persist_ws)) return 1;
     for (int l = 0; l < L; ++l)
         if (!d.w_hh[l] || (l > 0 && !d.w_ih[l])) return 1;
-    if (!aligned16(d.gates) || !aligned16(d.cs) || !aligned16(g.dgates) || !aligned16(g.dh) || !aligned16(g.dc)) return 1;
-    if (g.dy && (!aligned16(g.dy) || g.dy_stride_t % 4 || g.dy_stride_b % 4)) return 1;
-    if ((g.dhT && !aligned16(g.dhT)) || (g.dcT && !aligned16(g.dcT))) return 1;
+    if (!grads_aligned(d, g)) return 1;
+    for (int l = 0; l < L; ++l)      // the k-major copies are optional, but must be 16-byte aligned to be used
+        if ((d.w_hhT[l] && !aligned16(d.w_hhT[l])) || (l > 0 && d.w_ihT[l] && !aligned16(d.w_ihT[l]))) return 1;
     const int lds_bytes = per * 4096;
     static int attr_set = 0;
     if (attr_set == 0) {
@@ -460,15 +519,31 @@ int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g,
     char* ws = reinterpret_cast<char*>(g.persist_ws);
     // the barrier block and the dG exchange buffer start from zero (rows >= B and not-yet-written slots read as zero)
     MMQG_TRY(copy_or_zero_f32(reinterpret_cast<float*>(ws), nullptr, wl.part / 4, s));
+    const int64_t BH = (int64_t)B * H, G4 = (int64_t)B * 4 * H;
     BwdArgs a{};
-    a.T = T; a.B = B; a.L = L; a.H = H; a.G = G; a.Cper = per;
-    for (int l = 0; l < L; ++l) { a.w_hh[l] = d.w_hh[l]; a.w_ih[l] = d.w_ih[l]; }
-    a.gates = d.gates; a.cs = d.cs; a.lens = d.lens;
-    a.dy = g.dy; a.dy_stride_t = g.dy_stride_t; a.dy_stride_b = g.dy_stride_b;
-    a.dhT = g.dhT; a.dcT = g.dcT;
-    a.dgates = g.dgates; a.dh_out = g.dh; a.dc_out = g.dc;
+    a.B = B; a.L = L; a.NL = NL; a.H = H; a.G = G; a.Cper = per;
+    a.ndiag = std::max(T + L - 1, aux ? d2->T : 0);
+    for (int l = 0; l < L; ++l) {
+        CellLayer& c = a.lay[l];
+        c.w_hh = d.w_hh[l]; c.w_hhT = d.w_hhT[l];
+        c.gates = d.gates + (int64_t)l * T * G4; c.cs = d.cs + (int64_t)l * (T + 1) * BH; c.lens = d.lens;
+        if (l == L - 1) { c.dy = g.dy; c.dy_stride_t = g.dy_stride_t; c.dy_stride_b = g.dy_stride_b; }
+        c.dhT = g.dhT ? g.dhT + l * BH : nullptr; c.dcT = g.dcT ? g.dcT + l * BH : nullptr;
+        c.dgates = g.dgates + (int64_t)l * T * G4; c.dh_out = g.dh + l * BH; c.dc_out = g.dc + l * BH;
+        c.T = T; c.doff = L - 1 - l;
+        a.w_ih[l] = l > 0 ? d.w_ih[l] : nullptr; a.w_ihT[l] = l > 0 ? d.w_ihT[l] : nullptr;
+    }
+    if (aux) {
+        CellLayer& c = a.lay[L];
+        c.w_hh = d2->w_hh[0]; c.w_hhT = (d2->w_hhT[0] && aligned16(d2->w_hhT[0])) ? d2->w_hhT[0] : nullptr;
+        c.gates = d2->gates; c.cs = d2->cs; c.lens = d2->lens;
+        c.dy = g2->dy; c.dy_stride_t = g2->dy_stride_t; c.dy_stride_b = g2->dy_stride_b;
+        c.dhT = g2->dhT; c.dcT = g2->dcT;
+        c.dgates = g2->dgates; c.dh_out = g2->dh; c.dc_out = g2->dc;
+        c.T = d2->T; c.doff = 0;
+    }
     a.drop = (d.training && d.dropout_p > 0.f && L > 1) ? 1 : 0;
-    a.drop_p = a.drop ? d.dropout_p : 0.f; a.seed = d.seed; a.stream_base = d.stream_base; a.seed_off = d.seed_offset;
+    a.drop_p = a.drop ? d.dropout_p : 0.f; a.seed = d.seed; a.stream_base = d.stream_base; a.seed_off = d.seed_offset; a.T0 = T;
     a.bar = reinterpret_cast<gb::XBar*>(ws + wl.bar);
     a.dgx = reinterpret_cast<float*>(ws + wl.dgx);
     a.part = reinterpret_cast<float*>(ws + wl.part);
@@ -478,7 +553,7 @@ int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g,
     a.expect_wg = (unsigned)(G + persist_test_extra_wg());
     a.max_spins = persist_test_max_spins() ? persist_test_max_spins() : gb::kDefaultSpins;
     a.trace = nullptr;
-    if (g_btrace_buf && (int64_t)G * (T + L - 1) * 6 <= g_btrace_words) a.trace = g_btrace_buf;
+    if (g_btrace_buf && (int64_t)G * a.ndiag * 6 <= g_btrace_words) a.trace = g_btrace_buf;
     if (a.trace) hipLaunchKernelGGL(lstm_persist_bwd_kernel<true>, dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
     else hipLaunchKernelGGL(lstm_persist_bwd_kernel<false>, dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
     g_persist_bwd_launches += 1;

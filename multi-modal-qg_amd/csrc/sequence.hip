@@ -242,6 +242,45 @@ static bool lstm_wavefront_bwd_ok(const mmqg_lstm_seq& d, const mmqg_lstm_seq_gr
     return true;
 }
 
+// gradient of the initial state after the persistent backward: what the kernel left in dh (the carry) + dgates_l(0) W_hh_l
+static int initial_state_grads_after_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s) {
+    const int T = d.T, B = d.B, H = d.H, L = d.L;
+    const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
+    for (int l = 0; l < L && (g.dh0 || g.dc0); ++l) {
+        if (g.dh0) {
+            MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, 4 * H, g.dgates + (int64_t)l * T * G, 4 * H, d.w_hh[l], H,
+                              nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 1, g.dh + l * BH, H, -1, s));
+            MMQG_TRY(copy_or_zero(g.dh0 + l * BH, g.dh + l * BH, (size_t)BH, s));
+        }
+        if (g.dc0) MMQG_TRY(copy_or_zero(g.dc0 + l * BH, g.dc + l * BH, (size_t)BH, s));
+    }
+    return 0;
+}
+
+int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s);
+
+// The backward TIME LOOPS (phase 1) of two independent stacks: the second one a single layer of the same batch and
+// width (the frame LSTM beside the text encoder).  ONE persistent launch when persist_bwd.hip takes the pair, otherwise
+// each stack's own loop (same results).  The callers run phase 2 (weight gradients, dx) of each afterwards.
+int lstm_seq_bwd_pair(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, const mmqg_lstm_seq& d2, const mmqg_lstm_seq_grad& g2,
+                      hipStream_t s) {
+    MMQG_TRY(check_lstm(d, "lstm_seq_bwd_pair"));
+    MMQG_TRY(check_lstm(d2, "lstm_seq_bwd_pair (second stack)"));
+    if (d.B > 0 && d.T > 0 && d2.B > 0 && d2.T > 0 && g.persist_ws && !g_no_fuse() && g.dgates && g.dh && g.dc && g2.dgates &&
+        g2.dh && g2.dc) {
+        const int rc = lstm_seq_bwd_persistent(d, g, &d2, &g2, s);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            MMQG_TRY(initial_state_grads_after_persistent(d, g, s));
+            return initial_state_grads_after_persistent(d2, g2, s);
+        }
+    }
+    mmqg_lstm_seq_grad a = g, b = g2;
+    a.phase = 1; b.phase = 1;
+    MMQG_TRY(lstm_seq_bwd(d, a, s));
+    return lstm_seq_bwd(d2, b, s);
+}
+
 int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_t s) {
     MMQG_TRY(check_lstm(d, "lstm_seq_bwd"));
     if (d.B == 0 || d.T == 0) return 0;
@@ -255,19 +294,11 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
     const bool do_wgrad = g.phase != 1;
     bool do_loop = g.phase != 2;
     if (do_loop && g.persist_ws && !g_no_fuse()) {      // all anti-diagonals as one persistent launch (persist_bwd.hip)
-        const int rc = lstm_seq_bwd_persistent(d, g, s);
+        const int rc = lstm_seq_bwd_persistent(d, g, nullptr, nullptr, s);
         if (rc < 0) return rc;
         if (rc == 0) {
             do_loop = false;
-            // gradient of the initial state: what the kernel left in dh (carry) + dgates_l(0) * W_hh_l
-            for (int l = 0; l < L && (g.dh0 || g.dc0); ++l) {
-                if (g.dh0) {
-                    MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_MN_MAJOR, B, H, 4 * H, g.dgates + (int64_t)l * T * G, 4 * H, d.w_hh[l],
-                                      H, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 1, g.dh + l * BH, H, -1, s));
-                    MMQG_TRY(copy_or_zero(g.dh0 + l * BH, g.dh + l * BH, (size_t)BH, s));
-                }
-                if (g.dc0) MMQG_TRY(copy_or_zero(g.dc0 + l * BH, g.dc + l * BH, (size_t)BH, s));
-            }
+            MMQG_TRY(initial_state_grads_after_persistent(d, g, s));
         }
     }
     if (do_loop && lstm_wavefront_bwd_ok(d, g)) {
@@ -393,6 +424,37 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
     }
     if (d.phase == 1) return 0;
     const float* htop_base = d.hs + (int64_t)(L - 1) * (T + 1) * BH;
+    // Look-ahead (as in the backward loop): the recurrent half of a layer-step, h_l(t) W_hh_l^T, only needs h_l(t), which
+    // exists one launch after cell (l, t) — a whole token before cell (l, t+1) uses it.  It is formed as an extra plain job
+    // of the NEXT launch on the dependent chain (cell (l+1, t); for the top layer the score product of token t+1) straight
+    // into the pre-activation slot gates_l[t+1], so every cell launch on the chain carries only the operand pair that
+    // really is late (layer 0: the contexts, K 1664 -> 1152; layers >= 1: the layer below, K 1024 -> 512).
+    // MEASURED (round 3, config 2): decoder forward 1.23 ms with it against 1.18 ms without — unlike the backward loop (K
+    // 4096 -> 2048 per cell launch, 14.9 -> 9.3 us) the forward launches are not shortened by carrying fewer k-chunks
+    // (their time is arguments + cold operands + epilogue + drain), and the extra jobs cost more than they save.  Kept
+    // as an opt-in A/B switch (MMQG_AHEAD_FWD=1), parity-tested.
+    static const bool ahead_fwd = [] { const char* e = getenv("MMQG_AHEAD_FWD"); return e && atoi(e) != 0; }();
+    bool ahead = ahead_fwd && !g_no_fuse() && (H % 4 == 0) && B <= 64;          // (B > 64: the wide cell kernel, no extra jobs)
+    for (int l = 0; l < L && ahead; ++l) {
+        const SkinnyPair a{d.hs, H, d.w_hh[l], H, H, 0};
+        const SkinnyPair b = l == 0 ? SkinnyPair{d.ctx, C, d.w_ih[0] + E, In0, C, 0} : SkinnyPair{d.hs, H, d.w_ih[l], H, H, 0};
+        ahead = skinny_usable(&a, 1) && skinny_usable(&b, 1) && (!drop || l == 0 || aligned16(d.hdrop));
+    }
+    auto rec_job = [&](int l, int t_next) {       // gates_l[t_next] (+)= h_l(t_next - 1) W_hh_l^T
+        SkinnyPlainJob j{};
+        j.M = B; j.N = 4 * H; j.npairs = 1; j.beta = l == 0 ? 1 : 0;      // layer 0: onto the hoisted embedded-word part + biases
+        j.C = d.gates + (int64_t)l * T * G + (int64_t)t_next * G; j.ldc = 4 * H;
+        j.pairs[0] = SkinnyPair{d.hs + (int64_t)l * (T + 1) * BH + (int64_t)t_next * BH, H, d.w_hh[l], H, H, 0};
+        return j;
+    };
+    if (ahead) {          // step 0: the recurrent halves from the initial state, up to three layers per launch
+        for (int l0 = 0; l0 < L; l0 += 3) {
+            SkinnyPlainJob pj[3];
+            const int nj = std::min(3, L - l0);
+            for (int i = 0; i < nj; ++i) pj[i] = rec_job(l0 + i, 0);
+            MMQG_TRY(skinny_plain_multi(pj, nj, s));
+        }
+    }
     for (int t = 0; t < T; ++t) {
         float* sc = d.scores + (int64_t)t * B * ldS;
         float* at = d.attn + (int64_t)t * B * ldS;
@@ -404,14 +466,23 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
             fused_attn = attn_fused_fwd(v, sc, ldS, htop_base + t * BH, H, d.w_attn + E, Q, H, at, ldS, cx, C, d.attn_ws,
                                         d.attn_ws_bytes, s);
         if (fused_attn < 0) return fused_attn;
+        const bool top_ahead = ahead && t > 0;        // gates_{L-1}[t] still lacks h_top(t-1) W_hh^T (step 0: done above)
         if (fused_attn != 0) {
             const SkinnyPair spr{htop_base + t * BH, H, d.w_attn + E, Q, H, 0};
-            if (!g_no_fuse() && skinny_usable(&spr, 1))
-                MMQG_TRY(skinny_plain(B, S, &spr, 1, nullptr, 1, sc, ldS, s));
-            else
+            if (!g_no_fuse() && skinny_usable(&spr, 1)) {
+                SkinnyPlainJob pj[2] = {};
+                pj[0].M = B; pj[0].N = S; pj[0].npairs = 1; pj[0].pairs[0] = spr; pj[0].beta = 1; pj[0].C = sc; pj[0].ldc = ldS;
+                if (top_ahead) pj[1] = rec_job(L - 1, t);
+                MMQG_TRY(skinny_plain_multi(pj, top_ahead ? 2 : 1, s));
+            } else {
                 MMQG_TRY(gemm_f32(MMQG_K_MAJOR, MMQG_K_MAJOR, B, S, H, htop_base + t * BH, H, d.w_attn + E, Q, nullptr, 0,
                                   nullptr, 0, 0, nullptr, nullptr, 1, sc, ldS, -1, s));
+                if (top_ahead) { const SkinnyPlainJob j = rec_job(L - 1, t); MMQG_TRY(skinny_plain_multi(&j, 1, s)); }
+            }
             MMQG_TRY(attn_softmax_context_fwd(v, sc, ldS, at, ldS, cx, C, s));
+        } else if (top_ahead) {
+            const SkinnyPlainJob j = rec_job(L - 1, t);
+            MMQG_TRY(skinny_plain_multi(&j, 1, s));
         }
         for (int l = 0; l < L; ++l) {
             float* hs_l = d.hs + (int64_t)l * (T + 1) * BH;
@@ -443,7 +514,18 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
             c.h_drop = (drop && l < L - 1) ? d.hdrop + (int64_t)l * T * BH + t * BH : nullptr;
             c.lens = d.lens; c.t = t;
             c.p = drop ? d.dropout_p : 0.f; c.seed = d.seed; c.seed_off = d.seed_offset; c.stream_id = d.stream_base + (uint64_t)l * T + t;
-            if (fused) {
+            if (fused && ahead) {
+                // only the late operand pair; the pre-activation slot already holds the recurrent half (+ for layer 0
+                // the hoisted part).  Rides along: the recurrent half of the layer below for the NEXT step.
+                SkinnyFwdJob job{};
+                job.pairs[0] = prs[0]; job.npairs = 1; job.gates_has_pre = 1;
+                job.bias1 = l == 0 ? nullptr : d.b_ih[l]; job.bias2 = l == 0 ? nullptr : d.b_hh[l];
+                job.cell = c;
+                SkinnyPlainJob look{};
+                const bool with_look = l > 0 && t + 1 < T;
+                if (with_look) look = rec_job(l - 1, t + 1);
+                MMQG_TRY(skinny_cell_fwd_plus(job, &look, with_look ? 1 : 0, s));
+            } else if (fused) {
                 // layer 0: the hoisted emb part + biases already sit in gates; layers > 0 start from the biases
                 if (l == 0) MMQG_TRY(skinny_cell_fwd(prs, 2, 1, nullptr, nullptr, c, s));
                 else MMQG_TRY(skinny_cell_fwd(prs, 2, 0, d.b_ih[l], d.b_hh[l], c, s));

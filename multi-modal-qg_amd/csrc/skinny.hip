@@ -89,12 +89,14 @@ __global__ __launch_bounds__(KS * 64, (MODE == MODE_FWD_CELL && KS == 4) ? 6 : (
     __shared__ float part[2][KS][16][17];
     MMQG_STAMP(0)
     const SkinnyK& a = batch.job[blockIdx.z];
-    if ((int)blockIdx.y * 16 >= a.M || (int)blockIdx.x * (MODE == MODE_FWD_CELL ? 4 : 16) >= (MODE == MODE_FWD_CELL ? a.H : a.N))
+    // a cell launch (either direction) may carry plain products as further jobs: look-ahead products of the time loops
+    const bool fwd_cell = MODE == MODE_FWD_CELL && !a.plain;
+    if ((int)blockIdx.y * 16 >= a.M || (int)blockIdx.x * (fwd_cell ? 4 : 16) >= (fwd_cell ? a.H : a.N))
         return;   // jobs of one launch may differ in size
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, kq = lane >> 4;      // MFMA operand slot of this lane: tile row/col c, k-slot kq
     const int m0 = blockIdx.y * 16;
-    const int n0 = blockIdx.x * (MODE == MODE_FWD_CELL ? 4 : 16);     // FWD: first hidden unit of the tile
+    const int n0 = blockIdx.x * (fwd_cell ? 4 : 16);                  // FWD cell: first hidden unit of the tile
     // Global loads are issued with 4 adjacent lanes on 64 contiguous bytes of ONE row (lr = lane>>2,
     // 16-byte segment ls = lane&3) so each lane quad is one cache-line access; a lane-per-row order
     // (what the MFMA operand layout wants) made every wave load 64 separate line accesses and the
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(KS * 64, (MODE == MODE_FWD_CELL && KS == 4) ? 6 : (
     const int src_lane = 4 * c + kq;
     const int ra = min(m0 + lr, a.M - 1);
     int nb;
-    if (MODE == MODE_FWD_CELL) nb = (lr >> 2) * a.H + n0 + (lr & 3);  // gate block (lr>>2), unit n0 + (lr&3)
+    if (fwd_cell) nb = (lr >> 2) * a.H + n0 + (lr & 3);               // gate block (lr>>2), unit n0 + (lr&3)
     else nb = min(n0 + lr, a.N - 1);
 
     const int per = (a.chunks + KS - 1) / KS;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(KS * 64, (MODE == MODE_FWD_CELL && KS == 4) ? 6 : (
     // may issue its operand loads)
     float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f, pf4 = 0.f, pf5 = 0.f, pf6 = 0.f;
     if (threadIdx.x < 256 && e_b < a.M) {
-        if (MODE == MODE_FWD_CELL) {
+        if (fwd_cell) {
             const int gc = (e_col >> 2) * a.H + n0 + (e_col & 3);
             if (a.gates_has_pre) pf0 = a.gates[(int64_t)e_b * 4 * a.H + gc];
             if (a.bias1) pf3 = a.bias1[gc];
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(KS * 64, (MODE == MODE_FWD_CELL && KS == 4) ? 6 : (
     __syncthreads();
     MMQG_STAMP(3)
     const int tid = threadIdx.x;
-    if (tid >= 256) { if (MODE != MODE_FWD_CELL) return; }
+    if (tid >= 256) { if (!fwd_cell) return; }
     const int row = (tid >> 4) & 15, col = tid & 15;
     float s = 0.f, sm = 0.f;
     if (tid < 256) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(KS * 64, (MODE == MODE_FWD_CELL && KS == 4) ? 6 : (
     }
     const int b = m0 + row;
 
-    if (MODE == MODE_PLAIN || (MODE == MODE_BWD_CELL && a.plain)) {
+    if (MODE == MODE_PLAIN || a.plain) {
         const int n = n0 + col;
         if (b < a.M && n < a.N) {
             float* dst = a.C + (int64_t)b * a.ldc + n;
@@ -501,7 +503,7 @@ int launch_skinny_batch(const SkinnyBatch& b, int njobs, hipStream_t s, const ch
     int64_t wgs = 0;       // workgroups that do work (the grid is the bounding box of the jobs)
     for (int i = 0; i < njobs; ++i) {
         const SkinnyK& k = b.job[i];
-        const int tn = MODE == MODE_FWD_CELL ? k.H / 4 : mmqg::ceil_div(k.N, 16), tm = mmqg::ceil_div(k.M, 16);
+        const int tn = (MODE == MODE_FWD_CELL && !k.plain) ? k.H / 4 : mmqg::ceil_div(k.N, 16), tm = mmqg::ceil_div(k.M, 16);
         tiles_n = std::max(tiles_n, tn);
         tiles_m = std::max(tiles_m, tm);
         wgs += (int64_t)tn * tm;
@@ -515,7 +517,7 @@ int launch_skinny_batch(const SkinnyBatch& b, int njobs, hipStream_t s, const ch
         bool ok = !no_wide;
         for (int i = 0; i < njobs && ok; ++i) {
             const SkinnyK& k = b.job[i];
-            ok = k.M > 64 && k.H % 4 == 0;
+            ok = k.M > 64 && k.H % 4 == 0 && !k.plain;
             const int tx = mmqg::ceil_div(k.H, kWideUnits), ty = mmqg::ceil_div(k.M, kWideRows);
             wide_wgs += (int64_t)tx * ty;
             wx = std::max(wx, tx); wy = std::max(wy, ty);
@@ -646,6 +648,14 @@ int skinny_cell_bwd_plus(const SkinnyBwdJob& cell, const SkinnyPlainJob* extra, 
     MMQG_TRY(fill_bwd_job(b.job[0], cell));
     for (int i = 0; i < nextra; ++i) MMQG_TRY(fill_plain_job(b.job[1 + i], extra[i]));
     return launch_skinny_batch<MODE_BWD_CELL>(b, 1 + nextra, s, "skinny_cell_bwd");
+}
+
+int skinny_cell_fwd_plus(const SkinnyFwdJob& cell, const SkinnyPlainJob* extra, int nextra, hipStream_t s) {
+    MMQG_REQUIRE(nextra >= 0 && nextra <= 2, "skinny_cell_fwd_plus: at most 2 extra products");
+    SkinnyBatch b{};
+    MMQG_TRY(fill_fwd_job(b.job[0], cell));
+    for (int i = 0; i < nextra; ++i) MMQG_TRY(fill_plain_job(b.job[1 + i], extra[i]));
+    return launch_skinny_batch<MODE_FWD_CELL>(b, 1 + nextra, s, "skinny_cell_fwd");
 }
 
 int skinny_cell_fwd(const SkinnyPair* pairs, int npairs, int gates_has_pre, const float* bias1, const float* bias2,

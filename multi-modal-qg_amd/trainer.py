@@ -102,13 +102,33 @@ class BatchedTrainer:
         self._audio_rows = 0
         # (stream priorities were tried both ways — side low, chain high — and change nothing: the range on this
         # stack is only (0, -1) and workgroup arbitration between queues does not follow it)
-        self._side = torch.cuda.Stream(device=self.dev)
+        self._side = self._make_side_stream()
         self.chain_first = os.environ.get("MMQG_SIDE_FIRST", "0") != "1"
         if os.environ.get("MMQG_NO_AHEAD", "0") != "1":      # look-ahead recurrent products in the decoder's backward loop
             self.g_dec.dh_pre = self.ws["dpre_d"].data_ptr()
         self.reducer = GradReducer(self.flat_g, trainer_buckets(self.segments, self.n_params), self.pg)
         if self.distributed:
             broadcast_parameters(self.flat_p, self.pg)
+
+    def _make_side_stream(self):
+        """The second stream of the step.  MMQG_SIDE_CU_MASK=n (A/B switch) confines it to n of the CUs
+        (hipExtStreamCreateWithCUMask; every 256/(256-n)-th CU is left out, so the remainder is spread over all XCDs),
+        to see whether the large side-branch GEMMs then stop starving the chain kernels of the main stream."""
+        n = int(os.environ.get("MMQG_SIDE_CU_MASK", "0"))
+        if n <= 0 or n >= 256:
+            return torch.cuda.Stream(device=self.dev)
+        hip = C.CDLL("libamdhip64.so")
+        drop_every = max(2, round(256 / (256 - n)))
+        bits = [0 if (i % drop_every) == drop_every - 1 else 1 for i in range(256)]
+        if os.environ.get("MMQG_SIDE_CU_MASK_LOW", "0") == "1":          # alternative: the first n CUs of the enumeration
+            bits = [1 if i < n else 0 for i in range(256)]
+        words = (C.c_uint32 * 8)(*[sum(b << k for k, b in enumerate(bits[32 * w:32 * w + 32])) for w in range(8)])
+        st = C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, words)
+        if rc != 0:
+            raise _lib.BackendError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+        self._side_cus = sum(bits)
+        return torch.cuda.ExternalStream(st.value, device=self.dev)
 
     # ------------------------------------------------------------------ parameter layout
     def _flatten_parameters(self):
@@ -556,6 +576,14 @@ class BatchedTrainer:
         if part == "dec":
             return
 
+        # Single GPU: the frame LSTM's backward time loop rides in the text encoder's persistent backward launch (both
+        # need only what the decoder's loop has just produced; csrc/persist_bwd.hip) instead of being a chain of eight
+        # launches on the other branch; only its weight gradients stay there.  Data parallel keeps it on the side branch:
+        # there the frame-encoder bucket's all-reduce should start as early as possible.
+        pair = part == "all" and self.chain_first and bool(self.g_text.persist_ws) and \
+            os.environ.get("MMQG_NO_BWD_PAIR", "0") != "1"
+        pair_done = []
+
         def enc_side(which: str = "both"):   # decoder weight gradients ("s1"), frame encoder backward ("s2")
             s2 = ops._stream()
             if which in ("both", "s1"):
@@ -568,8 +596,11 @@ class BatchedTrainer:
                     # from the side stream so it runs beside the text encoder's backward
                     self.reducer.reduce("dec")
             if which in ("both", "s2"):
-                self.g_vid.phase = 0
+                if pair_done:                # its time loop ran in the text encoder's launch on the other stream
+                    torch.cuda.current_stream().wait_event(pair_done[0])
+                self.g_vid.phase = 2 if pair_done else 0
                 check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_vid), C.byref(self.g_vid), s2), "lstm_seq_bwd(frames)")
+                self.g_vid.phase = 0
                 if self._cnn_on:
                     check(lib.mmqg_frame_cnn_bwd(C.byref(self.d_cnn), C.byref(self.g_cnn), s2), "frame_cnn_bwd")
                 if self.distributed and not torch.cuda.is_current_stream_capturing():
@@ -581,8 +612,13 @@ class BatchedTrainer:
                 self._adam("early")
 
         def enc_chain():             # text encoder backward: the rest of the dependent chain
-            self.g_text.phase = 1
-            check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, loop)")
+            if pair:
+                check(lib.mmqg_lstm_seq_bwd_pair(C.byref(self.d_text), C.byref(self.g_text), C.byref(self.d_vid),
+                                                 C.byref(self.g_vid), s), "lstm_seq_bwd_pair(text + frames, loops)")
+                pair_done.append(self._mark())
+            else:
+                self.g_text.phase = 1
+                check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, loop)")
             self.g_text.phase = 2
             check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, wgrad)")
             self.g_text.phase = 0
