@@ -137,6 +137,12 @@ __global__ __launch_bounds__(KS * 64, (MODE == MODE_FWD_CELL && KS == 4) ? 6 : (
                 pf1 = a.c_new[e];
                 if (a.pre) pf6 = a.pre[e];
             }
+        } else if (n0 + e_col < a.N) {
+            // plain product: the accumulated-into output and the bias are requested now as well (the score product of a
+            // decode step adds onto scores that were hoisted milliseconds ago: a cold read that used to sit behind the
+            // operand loop)
+            if (a.beta) pf0 = a.C[(int64_t)e_b * a.ldc + n0 + e_col];
+            if (a.bias) pf1 = a.bias[n0 + e_col];
         }
     }
 
@@ -232,12 +238,7 @@ __global__ __launch_bounds__(KS * 64, (MODE == MODE_FWD_CELL && KS == 4) ? 6 : (
 
     if (MODE == MODE_PLAIN || a.plain) {
         const int n = n0 + col;
-        if (b < a.M && n < a.N) {
-            float* dst = a.C + (int64_t)b * a.ldc + n;
-            float v = s + (a.bias ? a.bias[n] : 0.f);
-            if (a.beta) v += *dst;
-            *dst = v;
-        }
+        if (b < a.M && n < a.N) a.C[(int64_t)b * a.ldc + n] = s + pf0 + pf1;      // (row, col) == (e_row, e_col): prefetched above
         return;
     }
 

@@ -29,7 +29,7 @@ def main():
     src = os.path.join(ROOT, "multi-modal-qg_amd", "csrc", "attention.hip")
     rec = {"kernel": rows[0]["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", ""),
            "launches": len(d), "us_per_launch": round(sum(d) / len(d) / 1e3, 3), "min_us": min(d) / 1e3, "max_us": max(d) / 1e3,
-           "grid": sorted({int(r["Grid_Size"]) for r in rows}),
+           "grid": sorted({int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0) for r in rows}),
            "source_sha": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
            "from": "rocprofv3 --kernel-trace of `bench.py --workload %s --kernel-iters 0`: step launches only" % workload}
     data = json.load(open(out)) if os.path.exists(out) else {}

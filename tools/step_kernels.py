@@ -10,4 +10,4 @@ t0 = int(step[0]["Start_Timestamp"])
 for r in step:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-44:]
-    print(f"{(s - t0) / 1e3:8.1f} q{r['Queue_Id']:>2s} {(e - s) / 1e3:7.1f} {n} grid={r.get('Grid_Size', '?')}")
+    print(f"{(s - t0) / 1e3:8.1f} q{r['Queue_Id']:>2s} {(e - s) / 1e3:7.1f} {n} grid={r.get('Grid_Size') or r.get('Grid_Size_X', '?')}")
