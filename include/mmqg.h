@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMQG_ABI_VERSION 7
+#define MMQG_ABI_VERSION 8
 #define MMQG_MAX_LAYERS 8
 
 typedef void* mmqg_stream; /* hipStream_t */
@@ -261,6 +261,10 @@ typedef struct {
                                                        and kept in LDS, partial products meeting through an exchange
                                                        buffer behind a device-wide barrier).  Same residency rule and
                                                        failure reporting as mmqg_lstm_seq.persist_ws */
+    float* wide_ws; int64_t wide_ws_bytes;          /* optional workspace for batches over 64 rows (size from
+                                                       mmqg_wide_ws_bytes, 16-byte aligned, zero-filled once): the
+                                                       backward layer-steps then run on 64 x 32 tiles whose k slices
+                                                       meet at a ticket instead of 16 x 16 tiles */
 } mmqg_lstm_seq_grad;
 
 int mmqg_lstm_seq_fwd(const mmqg_lstm_seq* d, mmqg_stream stream);
@@ -295,6 +299,8 @@ int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_
  * Phase 2 (weight gradients, dx) of each stack is the caller's next call.  g->phase / g2->phase are ignored. */
 int mmqg_lstm_seq_bwd_pair(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, const mmqg_lstm_seq* d2,
                            const mmqg_lstm_seq_grad* g2, mmqg_stream stream);
+/* bytes of the wide_ws workspaces for a batch of B rows and products up to max_N columns wide; 0 = not used (B <= 64) */
+int64_t mmqg_wide_ws_bytes(int B, int max_N);
 /* bytes of mmqg_lstm_seq_grad.persist_ws for this shape; 0 = shape not taken (B > 64, H not a multiple of 64 or
  * below 128, weights beyond the chip's LDS, ...): the backward then runs one launch per anti-diagonal */
 int64_t mmqg_lstm_seq_bwd_persist_ws_bytes(int T, int B, int L, int H);
@@ -361,6 +367,8 @@ typedef struct {
      * one step ahead of its use, as an extra job of a launch that is on the dependent chain anyway, so the
      * cell kernels of the chain carry only the operand pair that really is late. */
     float* dh_pre;
+    float* wide_ws; int64_t wide_ws_bytes;          /* as mmqg_lstm_seq_grad.wide_ws (max_N = the widest product of the
+                                                       loop: max(H, H + Da + Dv, ld_attn)) */
 } mmqg_decoder_seq_grad;
 
 /* mmqg_decoder_decode: the free-running decode loop of validate() / evaluate()

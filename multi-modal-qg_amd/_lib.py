@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmqg_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_LAYERS = 8
 
 K_MAJOR, MN_MAJOR = 0, 1
@@ -57,7 +57,7 @@ class LstmSeqGrad(C.Structure):
                 ("dx", c_f), ("lddx", C.c_int32),
                 ("dw_ih", _PTRS), ("dw_hh", _PTRS), ("db_ih", _PTRS), ("db_hh", _PTRS),
                 ("dh0", c_f), ("dc0", c_f), ("phase", C.c_int32),
-                ("persist_ws", c_f), ("persist_ws_bytes", c_i64)]
+                ("persist_ws", c_f), ("persist_ws_bytes", c_i64), ("wide_ws", c_f), ("wide_ws_bytes", c_i64)]
 
 
 class DecoderSeq(C.Structure):
@@ -94,7 +94,7 @@ class DecoderSeqGrad(C.Structure):
                 ("dw_ih", _PTRS), ("dw_hh", _PTRS), ("db_ih", _PTRS), ("db_hh", _PTRS),
                 ("n_text_rows", C.c_int32), ("dtext", c_f), ("dtext_stride_row", c_i64), ("dtext_stride_b", c_i64),
                 ("n_video_rows", C.c_int32), ("dvideo", c_f), ("dvideo_stride_row", c_i64), ("dvideo_stride_b", c_i64),
-                ("phase", C.c_int32), ("dh_pre", c_f)]
+                ("phase", C.c_int32), ("dh_pre", c_f), ("wide_ws", c_f), ("wide_ws_bytes", c_i64)]
 
 
 class TransposeJob(C.Structure):
@@ -175,6 +175,7 @@ SIGNATURES = {
     "mmqg_lstm_seq_fwd": [C.POINTER(LstmSeq), c_f],
     "mmqg_lstm_seq_persist_ws_bytes": [C.c_int, C.c_int, C.c_int, C.c_int],
     "mmqg_persist_launch_count": [],
+    "mmqg_wide_ws_bytes": [C.c_int, C.c_int],
     "mmqg_lstm_seq_bwd_persist_ws_bytes": [C.c_int, C.c_int, C.c_int, C.c_int],
     "mmqg_persist_bwd_launch_count": [],
     "mmqg_persist_bwd_set_trace": [c_f, c_i64],

@@ -80,6 +80,10 @@ struct SkinnyPair {
     int masked;                   // backward only: product goes through the layer's dropout mask
 };
 bool skinny_usable(const SkinnyPair* pairs, int npairs);
+// workspace of the wide (64 x 32 tiles, k slices meeting at a ticket) backward / plain kernel for batches over 64 rows:
+// set by an executor for the duration of its call, zero tickets at the end of the buffer
+void skinny_set_wide_ws(float* ws, int64_t bytes);
+int64_t skinny_wide_ws_bytes(int M, int max_N);
 int skinny_plain(int M, int N, const SkinnyPair* pairs, int npairs, const float* bias, int beta, float* C, int ldc,
                  hipStream_t s);
 // gates (+= if gates_has_pre) sum of pairs + bias1 + bias2, then the cell update of CellFwd

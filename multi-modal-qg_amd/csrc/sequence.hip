@@ -39,6 +39,12 @@ int check_lstm(const mmqg_lstm_seq& d, const char* who) {
 
 inline bool lstm_drop(const mmqg_lstm_seq& d) { return d.training && d.dropout_p > 0.f && d.L > 1; }
 
+// the wide backward / plain kernel's workspace is the caller's: handed to skinny.hip for the duration of one executor call
+struct WideWsScope {
+    WideWsScope(float* ws, int64_t bytes) { mmqg::skinny_set_wide_ws(ws, bytes); }
+    ~WideWsScope() { mmqg::skinny_set_wide_ws(nullptr, 0); }
+};
+
 // MMQG_NO_WAVEFRONT=1: layer-by-layer time loops (one fused launch per layer-step) for A/B comparisons
 inline bool g_no_wavefront() {
     static const bool v = [] { const char* e = getenv("MMQG_NO_WAVEFRONT"); return e && atoi(e) != 0; }();
@@ -291,6 +297,7 @@ int lstm_seq_bwd(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g, hipStream_
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
     const bool drop = lstm_drop(d);
     MMQG_REQUIRE(g.phase >= 0 && g.phase <= 2, "lstm_seq_bwd: phase must be 0, 1 or 2");
+    const WideWsScope wide_scope(g.wide_ws, g.wide_ws_bytes);
     const bool do_wgrad = g.phase != 1;
     bool do_loop = g.phase != 2;
     if (do_loop && g.persist_ws && !g_no_fuse()) {      // all anti-diagonals as one persistent launch (persist_bwd.hip)
@@ -549,6 +556,7 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
     const int64_t BH = (int64_t)B * H, G = (int64_t)B * 4 * H;
     const bool drop = d.training && d.dropout_p > 0.f && L > 1;
     MMQG_REQUIRE(g.phase >= 0 && g.phase <= 2, "decoder_seq_bwd: phase must be 0, 1 or 2");
+    const WideWsScope wide_scope(g.wide_ws, g.wide_ws_bytes);
     const bool do_loop = g.phase != 2, do_wgrad = g.phase != 1;
     if (do_loop) {
     {

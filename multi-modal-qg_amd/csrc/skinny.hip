@@ -69,6 +69,12 @@ __device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const int32_t* off) 
 
 struct SkinnyBatch {
     SkinnyK job[3];      // blockIdx.z selects the job: independent layer-steps of one wavefront diagonal
+    // wide backward / plain kernel only: k slices per tile and the workspace their partial tiles meet in
+    int ksl;
+    float* ws;           // [job][tile_m][tile_n][slice][2 (plain | masked)][64][32] partial tiles, then the tickets
+    unsigned* tickets;   // [job][tile_m][tile_n], zero between launches
+    int ws_tiles_n;      // tile_n extent of the workspace indexing (largest job of the launch)
+    int ws_tiles_m;
 };
 
 // tools/skinny_probe.hip compiles this file with MMQG_SKINNY_TRACE to stamp the stages of a workgroup
@@ -452,6 +458,318 @@ __global__ __launch_bounds__(256, 1) void cell_fwd_wide_kernel(SkinnyBatch batch
     }
 }
 
+
+// Wide BACKWARD layer-step / plain product for batches over 64 rows (config 5: B = 128, H = 1024).  A
+// backward layer-step there is dh[128 x 1024] over K = 8192: 16 x 16 tiles make 512 workgroups pull 1 MB each through the
+// L2s (512 MB per layer-step, 91 us for 2.1 GFLOP).  Here a 4-wave workgroup owns 64 rows x 32 columns (a weight fragment
+// serves four row tiles, an activation fragment two column tiles: 0.375 MB per 16 x 16 output tile instead of 1 MB) and —
+// because 64 x 32 tiles alone leave only 64 workgroups per layer-step — the K range of a tile is cut into `ksl` slices
+// handled by different workgroups.  The slices meet WITHOUT atomics on the data and without fences: every workgroup
+// stores its partial tile(s) write-through (sc1), every wave drains its stores, one lane takes a ticket with a returning
+// agent-scope atomic, and the workgroup whose ticket is the last one loads the other slices with sc1 loads, sums them in
+// slice order (deterministic) and runs the epilogue (cell backward, or the plain product's bias / accumulate) for the
+// tile (cdna_hip_programming.md Guideline 16; MI355X_MICROARCH.md valid-forms table, first row).  The earlier attempt
+// with f32 atomics into a scratch tile plus a ticket lost to the 16 x 16 kernel.
+constexpr int kBwRows = 64, kBwCols = 32;
+
+__device__ __forceinline__ float ldg_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void wide_bwd_kernel(SkinnyBatch batch) {
+    __shared__ float part[2][4][kBwRows][kBwCols + 1];
+    __shared__ unsigned last_flag;
+    const SkinnyK& a = batch.job[blockIdx.z];
+    const int ksl = batch.ksl;
+    const int tn = blockIdx.x / ksl, slice = blockIdx.x - tn * ksl;
+    const int m0 = blockIdx.y * kBwRows, n0 = tn * kBwCols;
+    if (m0 >= a.M || n0 >= a.N) return;       // jobs of one launch may differ in size
+    const bool cell = MODE == MODE_BWD_CELL && !a.plain;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, kq = lane >> 4;
+    const int lr = lane >> 2, ls = lane & 3;
+    const int src_lane = 4 * c + kq;
+    int ra[4], nb[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ra[r] = min(m0 + 16 * r + lr, a.M - 1);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) nb[cc] = min(n0 + 16 * cc + lr, a.N - 1);
+    // this workgroup's k-chunks, then this wave's quarter of them
+    const int per_s = (a.chunks + ksl - 1) / ksl;
+    const int s0 = slice * per_s, s1 = min(a.chunks, s0 + per_s);
+    const int per = (max(s1 - s0, 0) + 3) / 4;
+    const int q0 = s0 + wave * per, q1 = min(s1, q0 + per);
+    f32x4 accp[4][2], accm[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) { accp[r][cc] = f32x4{0.f, 0.f, 0.f, 0.f}; accm[r][cc] = accp[r][cc]; }
+    bool any_masked = false;
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
+        const int pbeg = pi == 0 ? 0 : (pi == 1 ? a.cs1 : a.cs2);
+        const int pend = pi == 0 ? min(a.cs1, a.chunks) : (pi == 1 ? min(a.cs2, a.chunks) : a.chunks);
+        const bool masked = cell && a.p[pi].masked;
+        any_masked = any_masked || (masked && pend > pbeg);
+        const int lo = max(q0, pbeg), hi = min(q1, pend);
+        if (lo >= hi) continue;
+        const float* __restrict__ Ap[4];
+        const float* __restrict__ Bp[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ap[r] = a.p[pi].A + (int64_t)ra[r] * a.p[pi].lda;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) Bp[cc] = a.p[pi].B + (int64_t)nb[cc] * a.p[pi].ldb;
+        const int K = a.p[pi].K;
+        constexpr int U = 2;                  // k-chunks per step; the NEXT step's 12 sixteen-byte loads are in flight
+                                              // behind the current step's 64 MFMAs (no branch in the loop: addresses are
+                                              // clamped and out-of-range chunks are zeroed after the load)
+        float4 av[4][U], bv[2][U], an[4][U], bn[2][U];
+        auto fetch = [&](float4 (&fa)[4][U], float4 (&fb)[2][U], int q) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = min((q + u - pbeg) * 16 + 4 * ls, K - 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fa[r][u] = *reinterpret_cast<const float4*>(Ap[r] + max(k, 0));
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) fb[cc][u] = *reinterpret_cast<const float4*>(Bp[cc] + max(k, 0));
+            }
+        };
+        fetch(av, bv, lo);
+        for (int q = lo; q < hi; q += U) {
+            fetch(an, bn, min(q + U, hi - 1));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = q + u < hi && (q + u - pbeg) * 16 + 4 * ls < K;
+                if (!in) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) av[r][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) bv[cc][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    av[r][u].x = __shfl(av[r][u].x, src_lane, 64); av[r][u].y = __shfl(av[r][u].y, src_lane, 64);
+                    av[r][u].z = __shfl(av[r][u].z, src_lane, 64); av[r][u].w = __shfl(av[r][u].w, src_lane, 64);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    bv[cc][u].x = __shfl(bv[cc][u].x, src_lane, 64); bv[cc][u].y = __shfl(bv[cc][u].y, src_lane, 64);
+                    bv[cc][u].z = __shfl(bv[cc][u].z, src_lane, 64); bv[cc][u].w = __shfl(bv[cc][u].w, src_lane, 64);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (masked) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) {
+                            accm[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].x, bv[cc][u].x, accm[r][cc], 0, 0, 0);
+                            accm[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].y, bv[cc][u].y, accm[r][cc], 0, 0, 0);
+                            accm[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].z, bv[cc][u].z, accm[r][cc], 0, 0, 0);
+                            accm[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].w, bv[cc][u].w, accm[r][cc], 0, 0, 0);
+                        }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) {
+                            accp[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].x, bv[cc][u].x, accp[r][cc], 0, 0, 0);
+                            accp[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].y, bv[cc][u].y, accp[r][cc], 0, 0, 0);
+                            accp[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].z, bv[cc][u].z, accp[r][cc], 0, 0, 0);
+                            accp[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].w, bv[cc][u].w, accp[r][cc], 0, 0, 0);
+                        }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) av[r][u] = an[r][u];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) bv[cc][u] = bn[cc][u];
+            }
+        }
+    }
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                part[0][wave][16 * r + 4 * kq + e][16 * cc + c] = accp[r][cc][e];
+                part[1][wave][16 * r + 4 * kq + e][16 * cc + c] = accm[r][cc][e];
+            }
+    __syncthreads();
+    // thread -> (row, 8 consecutive columns) of the 64 x 32 tile
+    const int row = threadIdx.x >> 2, c8 = (threadIdx.x & 3) * 8;
+    f32x4 sp[2], sm[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = c8 + 4 * h + i;
+            sp[h][i] = part[0][0][row][cc] + part[0][1][row][cc] + part[0][2][row][cc] + part[0][3][row][cc];
+            sm[h][i] = part[1][0][row][cc] + part[1][1][row][cc] + part[1][2][row][cc] + part[1][3][row][cc];
+        }
+    if (ksl > 1) {
+        // ---- the slices of this tile meet: write-through partials (16-byte stores), drained, one ticket; the last one
+        // requests every slice's tile at once and sums in slice order
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int64_t tile_id = ((int64_t)blockIdx.z * batch.ws_tiles_m + blockIdx.y) * batch.ws_tiles_n + tn;
+        constexpr int kRec = 2 * kBwRows * kBwCols;                       // floats per (tile, slice): plain | masked
+        const int tile_bytes = ksl * kRec * 4;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(batch.ws + tile_id * ksl * kRec, 0, tile_bytes, 0x00020000);
+        const int my = (slice * kRec + row * kBwCols + c8) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sp[h]), rs, my + 16 * h, 0, 16);
+            if (any_masked) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sm[h]), rs, my + kBwRows * kBwCols * 4 + 16 * h, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(batch.tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = old == (unsigned)ksl - 1u ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        f32x4 vp[4][2], vm[4][2];
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int o = (min(sl, ksl - 1) * kRec + row * kBwCols + c8) * 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                vp[sl][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16 * h, 0, 16));
+                vm[sl][h] = any_masked ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o + kBwRows * kBwCols * 4 + 16 * h, 0, 16))
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { sp[h] = f32x4{0.f, 0.f, 0.f, 0.f}; sm[h] = sp[h]; }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const float w = sl < ksl ? 1.f : 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { sp[h] += w * vp[sl][h]; sm[h] += w * vm[sl][h]; }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(batch.tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int b = m0 + row;
+    if (b >= a.M) return;
+    if (!cell) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + c8 + 4 * h + i;
+                if (n < a.N) {
+                    float* dst = a.C + (int64_t)b * a.ldc + n;
+                    float v = sp[h][i] + (a.bias ? a.bias[n] : 0.f);
+                    if (a.beta) v += *dst;
+                    *dst = v;
+                }
+            }
+        return;
+    }
+    {
+        const int H = a.H;
+        const bool active = a.lens ? (a.t < a.lens[b]) : true;
+        float* dg = a.dgates + (int64_t)b * 4 * H;
+        const float* gr = a.gates_act + (int64_t)b * 4 * H;
+        const uint64_t seed = a.drop_p > 0.f ? eff_seed(a.seed, a.seed_off) : 0;
+        const bool need_mask = (any_masked || a.above) && a.drop_p > 0.f;
+        // whole 4-column groups with 16-byte aligned operands (every shape the executors produce): all operands of the
+        // thread's 8 elements are requested before the first is used
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+        const bool vec = (H % 4 == 0) && n0 + c8 + 8 <= H && !a.above && al16(a.carry) && al16(a.c_new) && al16(a.c_prev) &&
+                         al16(a.dc) && al16(a.gates_act) && al16(a.dgates) && (!a.pre || al16(a.pre)) &&
+                         (!a.extra || (al16(a.extra) && a.extra_stride_b % 4 == 0));
+        if (vec) {
+            f32x4 car[2], pre[2], ext[2], cn[2], cp[2], dcv[2], g4[4][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = n0 + c8 + 4 * h;
+                const int64_t e = (int64_t)b * H + j;
+                car[h] = *reinterpret_cast<const f32x4*>(a.carry + e);
+                pre[h] = a.pre ? *reinterpret_cast<const f32x4*>(a.pre + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+                ext[h] = (a.extra && active) ? *reinterpret_cast<const f32x4*>(a.extra + (int64_t)b * a.extra_stride_b + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+                cn[h] = *reinterpret_cast<const f32x4*>(a.c_new + e);
+                cp[h] = *reinterpret_cast<const f32x4*>(a.c_prev + e);
+                dcv[h] = *reinterpret_cast<const f32x4*>(a.dc + e);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) g4[g][h] = *reinterpret_cast<const f32x4*>(gr + g * H + j);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = n0 + c8 + 4 * h;
+                const int64_t e = (int64_t)b * H + j;
+                f32x4 mask = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (need_mask) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mask[i] = dropout_scale(seed, a.stream_id, (uint64_t)(e + i), a.drop_p);
+                }
+                f32x4 dh = sp[h] + car[h] + pre[h];
+                if (any_masked) dh += sm[h] * mask;
+                if (!active) {
+                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(dg + g * H + j) = z;
+                    *reinterpret_cast<f32x4*>(a.carry + e) = dh;         // state was carried forward, so is its gradient
+                    continue;
+                }
+                dh += ext[h];
+                const f32x4 gi = g4[0][h], gf = g4[1][h], gg = g4[2][h], go = g4[3][h];
+                f32x4 tc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tc[i] = tanhf(cn[h][i]);
+                const f32x4 dct = dcv[h] + dh * go * (1.f - tc * tc);
+                *reinterpret_cast<f32x4*>(dg + j) = dct * gg * gi * (1.f - gi);
+                *reinterpret_cast<f32x4*>(dg + H + j) = dct * cp[h] * gf * (1.f - gf);
+                *reinterpret_cast<f32x4*>(dg + 2 * H + j) = dct * gi * (1.f - gg * gg);
+                *reinterpret_cast<f32x4*>(dg + 3 * H + j) = dh * tc * go * (1.f - go);
+                *reinterpret_cast<f32x4*>(a.dc + e) = dct * gf;
+                *reinterpret_cast<f32x4*>(a.carry + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = n0 + c8 + 4 * h + i;
+                if (j >= H) continue;
+                const int64_t e = (int64_t)b * H + j;
+                float mask = 1.f;
+                if (need_mask) mask = dropout_scale(seed, a.stream_id, (uint64_t)e, a.drop_p);
+                float dh = sp[h][i] + a.carry[e] + (a.pre ? a.pre[e] : 0.f);
+                if (any_masked) dh += sm[h][i] * mask;
+                if (!active) {
+                    dg[j] = 0.f; dg[H + j] = 0.f; dg[2 * H + j] = 0.f; dg[3 * H + j] = 0.f;
+                    a.carry[e] = dh;                    // state was carried forward, so is its gradient
+                    continue;
+                }
+                if (a.above) dh += a.above[(int64_t)b * a.above_stride_b + j] * mask;
+                if (a.extra) dh += a.extra[(int64_t)b * a.extra_stride_b + j];
+                const float gi = gr[j], gf = gr[H + j], gg = gr[2 * H + j], go = gr[3 * H + j];
+                const float tc = tanhf(a.c_new[e]);
+                const float dct = a.dc[e] + dh * go * (1.f - tc * tc);
+                dg[j] = dct * gg * gi * (1.f - gi);
+                dg[H + j] = dct * a.c_prev[e] * gf * (1.f - gf);
+                dg[2 * H + j] = dct * gi * (1.f - gg * gg);
+                dg[3 * H + j] = dh * tc * go * (1.f - go);
+                a.dc[e] = dct * gf;
+                a.carry[e] = 0.f;
+            }
+    }
+}
+
 // dst[c][r] = src[r][c]   (rows x cols -> cols x rows), 32x32 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int ld_src, int rows, int cols,
                                                         float* __restrict__ dst, int ld_dst) {
@@ -498,8 +816,55 @@ bool pair_ok(const mmqg::SkinnyPair& p) {
            mmqg::aligned16(p.B);
 }
 
+// workspace of the wide backward / plain kernel, set for the duration of an executor call (sequence.hip)
+thread_local float* t_wide_ws = nullptr;
+thread_local int64_t t_wide_bytes = 0;
+
+// The tickets sit at a FIXED place — the first kWideTicketBytes of the workspace — whatever the launch's tile grid
+// and slice count: launches of different geometry share one workspace, and a ticket word that another launch's
+// partial tiles had overwritten would never count up to ksl.
+constexpr int kWideTicketBytes = 8192;
+inline int64_t wide_ws_need(int njobs, int tiles_m, int tiles_n, int ksl) {
+    if ((int64_t)njobs * tiles_m * tiles_n * 4 > kWideTicketBytes) return -1;
+    return kWideTicketBytes + (int64_t)njobs * tiles_m * tiles_n * ksl * 2 * kBwRows * kBwCols * 4;
+}
+
+// batches over 64 rows: 64 x 32 tiles with k slices (wide_bwd_kernel); 0 = launched, 1 = not taken
+template <int MODE>
+int try_wide_bwd(const SkinnyBatch& b0, int njobs, hipStream_t s, const char* what) {
+    static const bool off = [] { const char* e = getenv("MMQG_NO_WIDE_BWD"); return e && atoi(e) != 0; }();
+    if (off || !t_wide_ws) return 1;
+    int maxM = 0, maxN = 0, min_chunks = 1 << 30;
+    int64_t tiles = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const SkinnyK& k = b0.job[i];
+        if (k.M <= 64) return 1;                         // the 16 x 16 kernel serves small batches
+        maxM = std::max(maxM, k.M); maxN = std::max(maxN, k.N);
+        min_chunks = std::min(min_chunks, k.chunks);
+        tiles += (int64_t)mmqg::ceil_div(k.M, kBwRows) * mmqg::ceil_div(k.N, kBwCols);
+    }
+    const int tiles_m = mmqg::ceil_div(maxM, kBwRows), tiles_n = mmqg::ceil_div(maxN, kBwCols);
+    // k slices: enough workgroups for two per CU, at least 32 k-chunks (512 k) per slice
+    static const int max_ksl = [] { const char* e = getenv("MMQG_WIDE_MAX_KSL"); return e ? atoi(e) : 4; }();
+    static const int only = [] { const char* e = getenv("MMQG_WIDE_ONLY"); return e ? atoi(e) : 0; }();   // debug: 1 = single-job launches only, 2 = multi-job only
+    if ((only == 1 && njobs != 1) || (only == 2 && njobs == 1)) return 1;
+    int ksl = 1;
+    while (ksl < max_ksl && tiles * ksl < 512 && min_chunks / (2 * ksl) >= 32) ksl *= 2;
+    const int64_t need = wide_ws_need(njobs, tiles_m, tiles_n, ksl);
+    if (need < 0 || need > t_wide_bytes || !mmqg::aligned16(t_wide_ws)) return 1;
+    SkinnyBatch b = b0;
+    b.ksl = ksl; b.ws = t_wide_ws + kWideTicketBytes / 4; b.tickets = reinterpret_cast<unsigned*>(t_wide_ws);
+    b.ws_tiles_n = tiles_n; b.ws_tiles_m = tiles_m;
+    hipLaunchKernelGGL((wide_bwd_kernel<MODE>), dim3(tiles_n * ksl, tiles_m, njobs), dim3(256), 0, s, b);
+    return mmqg::check_launch(what);
+}
+
 template <int MODE>
 int launch_skinny_batch(const SkinnyBatch& b, int njobs, hipStream_t s, const char* what) {
+    if (MODE != MODE_FWD_CELL) {
+        const int rc = try_wide_bwd<MODE == MODE_FWD_CELL ? MODE_PLAIN : MODE>(b, njobs, s, what);
+        if (rc <= 0) return rc;
+    }
     int tiles_n = 0, tiles_m = 0, chunks = 0;
     int64_t wgs = 0;       // workgroups that do work (the grid is the bounding box of the jobs)
     for (int i = 0; i < njobs; ++i) {
@@ -571,6 +936,15 @@ int fill_pairs(SkinnyK& k, const mmqg::SkinnyPair* pairs, int npairs, const char
 }  // namespace
 
 namespace mmqg {
+
+// the caller-owned workspace of the wide backward / plain kernel for the executor call in progress on this thread
+// (null = none: batches over 64 rows then take the 16 x 16 kernel); the ticket words at its start must be zero
+void skinny_set_wide_ws(float* ws, int64_t bytes) { t_wide_ws = ws; t_wide_bytes = ws ? bytes : 0; }
+int64_t skinny_wide_ws_bytes(int M, int max_N) {
+    if (M <= 64 || max_N <= 0) return 0;
+    const int64_t n = wide_ws_need(3, ceil_div(M, kBwRows), ceil_div(max_N, kBwCols), 4);
+    return n < 0 ? 0 : n;
+}
 
 bool skinny_usable(const SkinnyPair* pairs, int npairs) {
     for (int i = 0; i < npairs; ++i)

@@ -332,6 +332,9 @@ class LSTMSeqFn(torch.autograd.Function):
         nws = int(_lib.load().mmqg_lstm_seq_bwd_persist_ws_bytes(T, B, L, H))   # > 0: the persistent backward takes this shape
         bws = torch.zeros((nws + 3) // 4, device=dev, dtype=torch.float32) if nws > 0 else None
         g.persist_ws, g.persist_ws_bytes = ptr(bws), nws
+        nwide = int(_lib.load().mmqg_wide_ws_bytes(B, H))              # > 0: batch over 64 rows, the wide backward layer-step
+        wws = torch.zeros((nwide + 3) // 4, device=dev, dtype=torch.float32) if nwide > 0 else None
+        g.wide_ws, g.wide_ws_bytes = ptr(wws), nwide
         dparams = [torch.zeros_like(p) for p in params]
         for l in range(L):
             g.dw_ih[l], g.dw_hh[l], g.db_ih[l], g.db_hh[l] = (p.data_ptr() for p in dparams[4 * l:4 * l + 4])

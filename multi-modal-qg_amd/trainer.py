@@ -292,6 +292,13 @@ class BatchedTrainer:
             w["pws_tb"] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)
             gt.persist_ws, gt.persist_ws_bytes = w["pws_tb"].data_ptr(), n
         self.d_text, self.g_text = dt, gt
+        # batches over 64 rows (config 5): workspaces of the wide backward layer-step kernel, one per stack (the frame
+        # encoder's backward runs beside the text encoder's)
+        for key, grad, width in (("wide_t", gt, H), ("wide_v", gv, self.Hv)):
+            n = int(_lib.load().mmqg_wide_ws_bytes(B, width))
+            if n > 0:
+                w[key] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)
+                grad.wide_ws, grad.wide_ws_bytes = w[key].data_ptr(), n
         # decoder
         dd, gd = _lib.DecoderSeq(), _lib.DecoderSeqGrad()
         dd.T, dd.B, dd.L, dd.H, dd.E = self.Td, B, L, H, self.E
@@ -330,6 +337,10 @@ class BatchedTrainer:
             if l > 0:
                 dd.w_ihT[l] = w["wihT_d"][l].data_ptr()
         dd.w_ih0cT, dd.w_attn_hT = w["wih0cT"].data_ptr(), w["wattn_hT"].data_ptr()
+        n = int(_lib.load().mmqg_wide_ws_bytes(B, max(H, self.Cw, self.ldS)))
+        if n > 0:
+            w["wide_d"] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)
+            gd.wide_ws, gd.wide_ws_bytes = w["wide_d"].data_ptr(), n
         # score product + softmax + contexts of a step as ONE launch (csrc/attention_fused.hip): opt-in.  Measured at
         # config 2 (round 3): 19.2 us per launch in isolation against 15.7 + 11.1 us for the two launches it replaces,
         # but 30.5 us inside the step, where every token's 54 MB value stream has flushed the score matrix from the L2s
@@ -506,6 +517,16 @@ class BatchedTrainer:
         self.d_dec.dropout_p = self.drop_dec if training else 0.0
         emb = self.dec.emb_layer.weight
 
+        # The k-major weight copies are only read by the BACKWARD loops: they go to the tail of the side branch, behind
+        # the frame encoder, and the main stream joins the branch at an event recorded IN FRONT of them — the transposes
+        # (96 MB of traffic, 50 us alone) then run beside the decoder's forward loop, a latency-bound chain that leaves the
+        # memory system idle, instead of in front of the text encoder.  The backward waits for them (self._tr_done).
+        # MEASURED (round 3, config 2, 30 steps): 4.683 ms with the transposes moved, 4.655 ms with them in front — the
+        # copies are no cheaper beside the chain than in front of it.  Opt-in A/B switch.
+        late_tr = os.environ.get("MMQG_TRANSPOSES_LATE", "0") == "1" and self.chain_first
+        self._tr_done = None
+        side_ready = []
+
         def side_branch():
             s = ops._stream()
             if self._cnn_on:
@@ -514,6 +535,10 @@ class BatchedTrainer:
             check(lib.mmqg_lstm_seq_fwd(C.byref(self.d_vid), s), "lstm_seq_fwd(frames)")
             if not hoists_first:
                 decoder_hoists(s)
+            if late_tr:
+                side_ready.append(self._mark())          # what the decoder's forward needs of this branch ends here
+                self._refresh_transposes()
+                self._tr_done = self._mark()
 
         def decoder_hoists(s):
             ops.embedding_fwd(emb, w["ids_d"], w["xemb_d"].view(-1, self.E))
@@ -521,7 +546,8 @@ class BatchedTrainer:
             check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd(hoists)")
             # always: a backward may follow an eval-mode forward too (tr.eval(); tr.forward_backward(batch)), and
             # its fused loops read the k-major copies
-            self._refresh_transposes()
+            if not late_tr:
+                self._refresh_transposes()
 
         # The text encoder's persistent time loop owns every CU while it runs, so whatever the other branch still has
         # queued at that point waits for its end and the decoder loop then waits for the branch.  The decoder's hoisted
@@ -546,7 +572,10 @@ class BatchedTrainer:
                 side_branch()
             chain()
         s = ops._stream()
-        self._join()
+        if side_ready:
+            torch.cuda.current_stream().wait_event(side_ready[0])
+        else:
+            self._join()
         self.d_dec.phase = 2
         check(lib.mmqg_decoder_seq_fwd(C.byref(self.d_dec), s), "decoder_seq_fwd(loop)")
         self.d_dec.phase = 0
@@ -572,6 +601,9 @@ class BatchedTrainer:
         htop = w["hs_d"][L - 1, 1:].reshape(R, H)
         demb = self.dec.emb_layer.weight.grad
         if part in ("all", "a", "dec"):
+            if self._tr_done is not None:            # the k-major weight copies were refreshed at the tail of the side branch
+                torch.cuda.current_stream().wait_event(self._tr_done)
+                self._tr_done = None
             self._backward_decoder(lib, w, s, logits, out, htop, R)
         if part == "dec":
             return
