@@ -366,22 +366,31 @@ __global__ __launch_bounds__(256, 1) void cell_fwd_wide_kernel(SkinnyBatch batch
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) Bp[cc] = a.p[pi].B + (int64_t)nb[cc] * a.p[pi].ldb;
         const int K = a.p[pi].K;
-        constexpr int U = 4;                  // k-chunks in flight per wave: 24 sixteen-byte loads
-        for (int q = lo; q < hi; q += U) {
-            float4 av[4][U], bv[2][U];
+        constexpr int U = 2;                  // k-chunks per step: the NEXT step's 12 sixteen-byte loads are in flight behind
+                                              // the current step's 64 MFMAs (branch-free loop: clamped addresses, chunks
+                                              // past the range zeroed after the load)
+        float4 av[4][U], bv[2][U], an[4][U], bn[2][U];
+        auto fetch = [&](float4 (&fa)[4][U], float4 (&fb)[2][U], int q) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = (q + u - pbeg) * 16 + 4 * ls;
-                const bool in = q + u < hi && k < K;
+                const int k = max(min((q + u - pbeg) * 16 + 4 * ls, K - 4), 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) av[r][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int r = 0; r < 4; ++r) fa[r][u] = *reinterpret_cast<const float4*>(Ap[r] + k);
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) bv[cc][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in) {
+                for (int cc = 0; cc < 2; ++cc) fb[cc][u] = *reinterpret_cast<const float4*>(Bp[cc] + k);
+            }
+        };
+        fetch(av, bv, lo);
+        for (int q = lo; q < hi; q += U) {
+            fetch(an, bn, min(q + U, hi - 1));
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) av[r][u] = *reinterpret_cast<const float4*>(Ap[r] + k);
+            for (int u = 0; u < U; ++u) {
+                const bool in = q + u < hi && (q + u - pbeg) * 16 + 4 * ls < K;
+                if (!in) {
 #pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) bv[cc][u] = *reinterpret_cast<const float4*>(Bp[cc] + k);
+                    for (int r = 0; r < 4; ++r) av[r][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) bv[cc][u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -411,6 +420,13 @@ __global__ __launch_bounds__(256, 1) void cell_fwd_wide_kernel(SkinnyBatch batch
                         acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].w, bv[cc][u].w, acc[r][cc], 0, 0, 0);
                     }
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) av[r][u] = an[r][u];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) bv[cc][u] = bn[cc][u];
+            }
         }
     }
     // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
