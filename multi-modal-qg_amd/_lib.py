@@ -206,6 +206,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: PyTorch-ROCm ships its own HIP runtime; whichever copy of libamdhip64 is mapped first serves the whole
+    # process, and a process in which this extension pulled in /opt/rocm's copy BEFORE torch initialised its own ends up
+    # launching through a runtime that sees no device ("no ROCm-capable device is detected" at the first kernel launch)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise BackendError(
             f"mmqg: HIP extension not built ({LIB_PATH} missing). Run `python -c 'import __graft_entry__ as g; "

@@ -511,8 +511,15 @@ def test_kernel_families_give_the_same_gradients_at_bench_size(mm, tmp_path):
 
     for workload, B, variants in (
             ("config2", 64, [("x3off", {"MMQG_GEMM_X3": "0"}, ()), ("nopersist", {"MMQG_NO_PERSIST": "1"}, ()),
-                             ("nofuse", {"MMQG_NO_FUSE": "1"}, ()), ("graph", {}, ("--graph",))]),
-            ("config5", 128, [("x3off", {"MMQG_GEMM_X3": "0"}, ()), ("nowide", {"MMQG_NO_WIDE": "1"}, ())])):
+                             ("nofuse", {"MMQG_NO_FUSE": "1"}, ()), ("graph", {}, ("--graph",)),
+                             # round 3: frame LSTM backward on its own chain instead of inside the text encoder's
+                             # persistent launch; the opt-in paths (fused score + attention launch, forward look-ahead
+                             # products, late weight transposes) must give the same step too
+                             ("nopair", {"MMQG_NO_BWD_PAIR": "1"}, ()), ("nopersistbwd", {"MMQG_NO_PERSIST_BWD": "1"}, ()),
+                             ("attnfuse", {"MMQG_ATTN_FUSE": "1"}, ()), ("aheadfwd", {"MMQG_AHEAD_FWD": "1"}, ()),
+                             ("latetr", {"MMQG_TRANSPOSES_LATE": "1"}, ("--graph",))]),
+            ("config5", 128, [("x3off", {"MMQG_GEMM_X3": "0"}, ()), ("nowide", {"MMQG_NO_WIDE": "1"}, ()),
+                              ("nowidebwd", {"MMQG_NO_WIDE_BWD": "1"}, ()), ("wideksl1", {"MMQG_WIDE_MAX_KSL": "1"}, ())])):
         ref = run("default", workload, B)
         assert int(ref["projection_kernel"]) == 2, "the default step must take the split-bf16 projection"
         if workload == "config2":
@@ -523,6 +530,10 @@ def test_kernel_families_give_the_same_gradients_at_bench_size(mm, tmp_path):
                 assert int(got["projection_kernel"]) != 2
             if tag in ("nopersist", "nofuse"):
                 assert int(got["persist_launches"]) == 0
+            if tag in ("nopersist", "nofuse", "nopersistbwd"):
+                assert int(got["persist_bwd_launches"]) == 0
+            elif workload == "config2":
+                assert int(got["persist_bwd_launches"]) > 0, "the persistent backward time loop did not run"
             close(got["loss"], ref["loss"], tol=1e-5, what=f"{workload} {tag}: loss vs default")
             close(got["logits"], ref["logits"], tol=2e-5, what=f"{workload} {tag}: logits vs default")
             for k in ref.files:
