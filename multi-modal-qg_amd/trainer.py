@@ -22,6 +22,7 @@ and therefore sits in two of the reference's three Adam optimizers (train.py:236
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Callable, Dict, List, Optional, Tuple
@@ -103,6 +104,7 @@ class BatchedTrainer:
         # (stream priorities were tried both ways — side low, chain high — and change nothing: the range on this
         # stack is only (0, -1) and workgroup arbitration between queues does not follow it)
         self._side = self._make_side_stream()
+        self._serial = os.environ.get("MMQG_SERIAL", "0") == "1"
         self.chain_first = os.environ.get("MMQG_SIDE_FIRST", "0") != "1"
         if os.environ.get("MMQG_NO_AHEAD", "0") != "1":      # look-ahead recurrent products in the decoder's backward loop
             self.g_dec.dh_pre = self.ws["dpre_d"].data_ptr()
@@ -489,11 +491,14 @@ class BatchedTrainer:
     #   backward: [vocab wgrad] || [vocab dgrad -> decoder loop], then
     #             [decoder weight grads, frame LSTM backward] || [text encoder backward]
     def _fork(self):
+        if self._serial:
+            return contextlib.nullcontext()
         self._side.wait_stream(torch.cuda.current_stream())
         return torch.cuda.stream(self._side)
 
     def _join(self):
-        torch.cuda.current_stream().wait_stream(self._side)
+        if not self._serial:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     # Issue order matters as much as the dependency graph: whoever is enqueued first runs first (host
     # enqueue in eager mode, node order in a captured graph).  So at every fork the kernels of the
@@ -505,6 +510,8 @@ class BatchedTrainer:
         return ev
 
     def _fork_from(self, ev):
+        if self._serial:         # MMQG_SERIAL=1 (A/B switch): everything on ONE stream, branch work behind the chain
+            return contextlib.nullcontext()
         self._side.wait_event(ev)
         return torch.cuda.stream(self._side)
 
@@ -618,6 +625,10 @@ class BatchedTrainer:
 
         def enc_side(which: str = "both"):   # decoder weight gradients ("s1"), frame encoder backward ("s2")
             s2 = ops._stream()
+            late = getattr(self, "_late_vocab", None)
+            if late is not None and which in ("both", "s1"):
+                self._late_vocab = None
+                late()
             if which in ("both", "s1"):
                 self.g_dec.phase = 2
                 check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s2), "decoder_seq_bwd(wgrad)")
@@ -692,6 +703,17 @@ class BatchedTrainer:
             self.g_dec.phase = 1
             check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s), "decoder_seq_bwd(loop)")
 
+        # MMQG_VOCAB_WGRAD=late|first (A/B): the projection's weight gradient behind the decoder's loop (with the other
+        # weight-gradient GEMMs) / in front of it on the chain, instead of beside the loop on the other stream
+        mode = os.environ.get("MMQG_VOCAB_WGRAD", "beside")
+        if mode == "late":
+            vocab_chain()
+            self._late_vocab = vocab_side
+            return
+        if mode == "first":
+            vocab_side()
+            vocab_chain()
+            return
         if self.chain_first:
             mark = self._mark()
             vocab_chain()
