@@ -50,7 +50,6 @@ struct FusedK {
     int R0, R1, R2, P0, P1, P2;          // rows per part / parts per modality (text, audio, video)
     int pstride;
     int64_t part_bytes;
-    int dbg;                             // timing experiments only (MMQG_ATTN_DBG bit mask; results are then wrong)
 };
 
 struct Seg {
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(256, 4) void attn_fused_fwd_kernel(FusedK a) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) dst[u] = *reinterpret_cast<const fx4*>(V + (int64_t)min(first + u * kGroups, last_row) * D);
     };
-    const bool stream = streamer && n_stream > 0 && !(a.dbg & 2);
+    const bool stream = streamer && n_stream > 0;
     if (stream) {
         fetch(cur, rg);
         fetch(nxt, rg + kU * kGroups);
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(256, 4) void attn_fused_fwd_kernel(FusedK a) {
         const int my_row = wave + 4 * lane;
         float my_s = my_row < R ? prow[my_row] : 0.f;
         const float* Wseg = a.W + (int64_t)(sg.seg_off + r0) * a.ld_w;
-        for (int i0 = wave; i0 < ((a.dbg & 1) ? 0 : R); i0 += 4 * kRowBatch) {
+        for (int i0 = wave; i0 < R; i0 += 4 * kRowBatch) {
             fx4 wv[kRowBatch][NQ];
 #pragma unroll
             for (int k = 0; k < kRowBatch; ++k) {
@@ -212,7 +211,6 @@ __global__ __launch_bounds__(256, 4) void attn_fused_fwd_kernel(FusedK a) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ux4, s), rs, prec_off + 16 + 16 * tid, 0, 16);
     }
     if (tid == 0) { st_rlx(prec, m); st_rlx(prec + 1, l); }
-    if (a.dbg & 4) return;
     // ---- ticket: every storing wave drains its write-through stores, then ONE lane adds (returning atomic)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -222,7 +220,7 @@ __global__ __launch_bounds__(256, 4) void attn_fused_fwd_kernel(FusedK a) {
         last_flag = (old == (unsigned)sg.P - 1u) ? 1u : 0u;
     }
     __syncthreads();
-    if (!last_flag || (a.dbg & 8)) return;
+    if (!last_flag) return;
 
     // ---- last arriver of (b, modality): merge the parts
     const float* pbase = a.part + ((int64_t)b * (a.P0 + a.P1 + a.P2) + sg.pfirst) * a.pstride;
@@ -349,8 +347,6 @@ int attn_fused_fwd(const mmqg_attn_values& v, const float* pre, int ld_s, const 
     k.part = ws; k.ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + pl.ticket_off);
     k.R0 = pl.R[0]; k.R1 = pl.R[1]; k.R2 = pl.R[2]; k.P0 = pl.P[0]; k.P1 = pl.P[1]; k.P2 = pl.P[2];
     k.pstride = pl.pstride; k.part_bytes = pl.part_bytes;
-    static const int dbg = [] { const char* e = getenv("MMQG_ATTN_DBG"); return e ? atoi(e) : 0; }();
-    k.dbg = dbg;
     const unsigned grid = (unsigned)(v.B * (pl.P[0] + pl.P[1] + pl.P[2]));
     if (Hq <= 256) hipLaunchKernelGGL(attn_fused_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, k);
     else if (Hq <= 512) hipLaunchKernelGGL(attn_fused_fwd_kernel<2>, dim3(grid), dim3(256), 0, s, k);

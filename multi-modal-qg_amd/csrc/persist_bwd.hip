@@ -154,7 +154,37 @@ __device__ __forceinline__ void seg_products(f32x4 (&ring)[kRing], const Rsrc& r
     }
 }
 
-template <bool TRACE>
+// the same for ONE column tile per wave (batches of at most 32 rows: two row blocks x four column tiles over the eight
+// waves instead of four row blocks x two tiles); two accumulator chains over alternating k (the 16x16x4 f32 MFMA has 40
+// cycles of dependent latency against 32 of issue)
+template <typename Rsrc>
+__device__ __forceinline__ void seg_products1(f32x4 (&ring)[kRing], const Rsrc& rs, int xoff, int n, const f32x4* wl, f32x4& acc) {
+    constexpr int chunk_bytes = 4 * kRows * 16;
+    f32x4 a0 = acc, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 + kRing < n; i0 += kRing) {
+#pragma unroll
+        for (int d = 0; d < kRing; ++d) {
+            const f32x4 w = wl[(i0 + d) * 256], x = ring[d];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, a1, 0, 0, 0);
+            ring[d] = ld_x(rs, xoff + (i0 + kRing + d) * chunk_bytes);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < kRing; ++d) {
+        const f32x4 w = wl[(n - kRing + d) * 256], x = ring[d];
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, a1, 0, 0, 0);
+    }
+    acc = a0 + a1;
+}
+
+// NARROW: B <= 32 (config 4): only two 16-row blocks hold questions
+template <bool TRACE, bool NARROW>
 __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -210,7 +240,7 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.dgx, 0, part_base + a.G * 2 * 4 * kRows * 16 * 4, 0x00020000);
 
     // ---- phase-A role of this wave: row block rb, column tiles 2 ch and 2 ch + 1
-    const int rb = wave & 3, ch = wave >> 2;
+    const int rb = NARROW ? (wave & 1) : (wave & 3), ch = NARROW ? (wave >> 1) : (wave >> 2);     // NARROW: ch = the wave's ONE column tile
     const int j = lane & 15, q = lane >> 4;
     const int xlane = (q * kRows + rb * 16 + j) * 16;                 // byte offset inside an operand chunk
     const int plane = ((rb * 16 + j) * 16 + 4 * q) * 4;               // byte offset inside a [64][16] partial column tile
@@ -219,7 +249,7 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
     const int per_layer = (H / 16) * 4;
     const int ntask = NL * per_layer;
     const int tau = blockIdx.x + a.G * wave;
-    const bool has_task = tau < ntask;
+    const bool has_task = tau < ntask && (tau & 3) * 16 < B;           // (row blocks past the batch: nothing to do, their exchange rows stay zero)
     const int tl = has_task ? tau / per_layer : 0;                    // cell layer
     const int tct = has_task ? (tau >> 2) % (H / 16) : 0;             // 16-unit tile
     const int trb = tau & 3;                                          // row block
@@ -299,6 +329,20 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
 #pragma unroll
             for (int d = 0; d < kRing; ++d) ring1[d] = ld_x(rs, xoff[1] + d * chunk_bytes);
         }
+        if (NARROW) {
+            if (son[0]) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                seg_products1(ring0, rs, xoff[0], sg[0].n, lds + sg[0].wbase + ch * 64 + lane, acc);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs,
+                                                       part_base + ((blockIdx.x * 2 + 0) * 4 + ch) * kRows * 16 * 4 + plane, 0, 16);
+            }
+            if (son[1]) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                seg_products1(ring1, rs, xoff[1], sg[1].n, lds + sg[1].wbase + ch * 64 + lane, acc);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rs,
+                                                       part_base + ((blockIdx.x * 2 + 1) * 4 + ch) * kRows * 16 * 4 + plane, 0, 16);
+            }
+        } else {
         if (son[0]) {
             f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
             seg_products(ring0, rs, xoff[0], sg[0].n, lds + sg[0].wbase + (2 * ch) * 64 + lane, acc0, acc1);
@@ -312,6 +356,7 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
             const int pb = part_base + ((blockIdx.x * 2 + 1) * 4 + 2 * ch) * kRows * 16 * 4 + plane;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc0), rs, pb, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc1), rs, pb + kRows * 16 * 4, 0, 16);
+        }
         }
         MMQG_BSTAMP(1)
         ok = gb::sync(bar);
@@ -494,11 +539,13 @@ int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g,
     const int lds_bytes = per * 4096;
     static int attr_set = 0;
     if (attr_set == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_bwd_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_persist_bwd_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+        hipError_t e = hipSuccess;
+        const void* fns[4] = {reinterpret_cast<const void*>(lstm_persist_bwd_kernel<false, false>),
+                              reinterpret_cast<const void*>(lstm_persist_bwd_kernel<true, false>),
+                              reinterpret_cast<const void*>(lstm_persist_bwd_kernel<false, true>),
+                              reinterpret_cast<const void*>(lstm_persist_bwd_kernel<true, true>)};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
         if (e != hipSuccess) (void)hipGetLastError();
         attr_set = e == hipSuccess ? 1 : -1;
     }
@@ -508,7 +555,7 @@ int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g,
         if (occ_lds != lds_bytes) {
             int nb = 0;
             const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                &nb, reinterpret_cast<const void*>(lstm_persist_bwd_kernel<false>), kThreads, (size_t)lds_bytes);
+                &nb, reinterpret_cast<const void*>(lstm_persist_bwd_kernel<false, false>), kThreads, (size_t)lds_bytes);
             if (e != hipSuccess) (void)hipGetLastError();
             occ_lds = lds_bytes; occ_ok = (e == hipSuccess && nb >= 1) ? 1 : 0;
         }
@@ -554,8 +601,12 @@ int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g,
     a.max_spins = persist_test_max_spins() ? persist_test_max_spins() : gb::kDefaultSpins;
     a.trace = nullptr;
     if (g_btrace_buf && (int64_t)G * a.ndiag * 6 <= g_btrace_words) a.trace = g_btrace_buf;
-    if (a.trace) hipLaunchKernelGGL(lstm_persist_bwd_kernel<true>, dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
-    else hipLaunchKernelGGL(lstm_persist_bwd_kernel<false>, dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
+    static const bool no_narrow = [] { const char* e = getenv("MMQG_PERSIST_BWD_NO_NARROW"); return e && atoi(e) != 0; }();
+    const bool narrow = B <= 32 && !no_narrow;
+    if (a.trace && narrow) hipLaunchKernelGGL((lstm_persist_bwd_kernel<true, true>), dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
+    else if (a.trace) hipLaunchKernelGGL((lstm_persist_bwd_kernel<true, false>), dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
+    else if (narrow) hipLaunchKernelGGL((lstm_persist_bwd_kernel<false, true>), dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
+    else hipLaunchKernelGGL((lstm_persist_bwd_kernel<false, false>), dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
     g_persist_bwd_launches += 1;
     persist_end(s);
     return check_launch("lstm_persist_bwd");

@@ -862,8 +862,6 @@ int try_wide_bwd(const SkinnyBatch& b0, int njobs, hipStream_t s, const char* wh
     const int tiles_m = mmqg::ceil_div(maxM, kBwRows), tiles_n = mmqg::ceil_div(maxN, kBwCols);
     // k slices: enough workgroups for two per CU, at least 32 k-chunks (512 k) per slice
     static const int max_ksl = [] { const char* e = getenv("MMQG_WIDE_MAX_KSL"); return e ? atoi(e) : 4; }();
-    static const int only = [] { const char* e = getenv("MMQG_WIDE_ONLY"); return e ? atoi(e) : 0; }();   // debug: 1 = single-job launches only, 2 = multi-job only
-    if ((only == 1 && njobs != 1) || (only == 2 && njobs == 1)) return 1;
     int ksl = 1;
     while (ksl < max_ksl && tiles * ksl < 512 && min_chunks / (2 * ksl) >= 32) ksl *= 2;
     const int64_t need = wide_ws_need(njobs, tiles_m, tiles_n, ksl);
