@@ -813,6 +813,21 @@ def test_transpose(mm):
     torch.cuda.synchronize()
     for a, a_d, d_d, r, c in keep:
         assert torch.equal(d_d[:, :r].cpu(), a[:, :c].t()) and torch.all(d_d[:, r:] == -2.0)
+    # a batch in which every job is 16-byte aligned with extents that are multiples of 4: the 64 x 64 float4 kernel (the
+    # weight matrices of the model: [4H][H], [4H][H + Da + Dv] sub-blocks with a leading dimension of their own, partial
+    # tiles at the edges)
+    shapes = [(2048, 512, 0, 0), (2048, 1152, 300, 0), (485, 512, 300, 3), (101, 36, 4, 7), (4, 4, 0, 0), (3, 8, 0, 1)]
+    jobs = (_lib.TransposeJob * len(shapes))()
+    keep = []
+    for j, (r, c, ps, pd) in zip(jobs, shapes):
+        a = torch.randn(r, c + ps, generator=g)
+        a_d, d_d = dev(a), torch.full((c, r + pd), -2.0, device="cuda")
+        keep.append((a, a_d, d_d, r, c, ps))
+        j.src, j.ld_src, j.rows, j.cols, j.dst, j.ld_dst = a_d.data_ptr() + 4 * ps, c + ps, r, c, d_d.data_ptr(), r + pd
+    _lib.check(_lib.load().mmqg_transpose_f32_batch(jobs, len(shapes), ops._stream()))
+    torch.cuda.synchronize()
+    for a, a_d, d_d, r, c, ps in keep:
+        assert torch.equal(d_d[:, :r].cpu(), a[:, ps:ps + c].t()) and torch.all(d_d[:, r:] == -2.0)
 
 
 # ------------------------------------------------------------------------------ edge cases
