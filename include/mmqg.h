@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMQG_ABI_VERSION 8
+#define MMQG_ABI_VERSION 9
 #define MMQG_MAX_LAYERS 8
 
 typedef void* mmqg_stream; /* hipStream_t */
@@ -344,6 +344,9 @@ typedef struct {
     float* attn_ws; int64_t attn_ws_bytes;          /* optional workspace (mmqg_attn_fused_ws_bytes(&values, H), zero-filled
                                                        once): the per-step score product, softmax and contexts then run
                                                        as ONE launch (mmqg_attn_scores_softmax_context_fwd) */
+    float* persist_ws; int64_t persist_ws_bytes;    /* optional workspace (mmqg_decoder_seq_persist_ws_bytes): the whole
+                                                       time loop then runs as ONE persistent launch when the shape is
+                                                       taken (opt-in: MMQG_PERSIST_DEC=1) */
 } mmqg_decoder_seq;
 
 typedef struct {
@@ -405,6 +408,13 @@ int mmqg_sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t se
                        int64_t* out_ids, mmqg_stream stream);
 
 int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream);
+/* bytes of mmqg_decoder_seq.persist_ws for this descriptor (T, B, L, H, E, values, ld_attn are read); 0 = the shape is
+ * not taken or MMQG_PERSIST_DEC is not set: the time loop then runs five launches per token */
+int64_t mmqg_decoder_seq_persist_ws_bytes(const mmqg_decoder_seq* d);
+/* diagnostics, as mmqg_persist_launch_count / mmqg_persist_set_trace (8 stamps per (workgroup, token): start, scores
+ * stored, barrier passed, contexts stored, barrier passed, layer 0 / 1 / 2 arrived) */
+int mmqg_decoder_persist_launch_count(void);
+int mmqg_decoder_persist_set_trace(uint64_t* buf, int64_t words);
 int mmqg_decoder_seq_bwd(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g, mmqg_stream stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmqg_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_LAYERS = 8
 
 K_MAJOR, MN_MAJOR = 0, 1
@@ -71,7 +71,8 @@ class DecoderSeq(C.Structure):
                 ("seed_offset", c_f),
                 ("scores", c_f), ("attn", c_f), ("ld_attn", C.c_int32),
                 ("ctx", c_f), ("gates", c_f), ("hs", c_f), ("cs", c_f), ("hdrop", c_f), ("phase", C.c_int32),
-                ("h0_stride_l", c_i64), ("attn_ws", c_f), ("attn_ws_bytes", c_i64)]
+                ("h0_stride_l", c_i64), ("attn_ws", c_f), ("attn_ws_bytes", c_i64),
+                ("persist_ws", c_f), ("persist_ws_bytes", c_i64)]
 
 
 class DecoderDecode(C.Structure):
@@ -179,6 +180,9 @@ SIGNATURES = {
     "mmqg_lstm_seq_bwd_persist_ws_bytes": [C.c_int, C.c_int, C.c_int, C.c_int],
     "mmqg_persist_bwd_launch_count": [],
     "mmqg_persist_bwd_set_trace": [c_f, c_i64],
+    "mmqg_decoder_seq_persist_ws_bytes": [C.POINTER(DecoderSeq)],
+    "mmqg_decoder_persist_launch_count": [],
+    "mmqg_decoder_persist_set_trace": [c_f, c_i64],
     "mmqg_persist_declined_count": [],
     "mmqg_persist_failures": [],
     "mmqg_persist_clear_failures": [],

@@ -187,6 +187,9 @@ int64_t mmqg_lstm_seq_persist_ws_bytes(int T, int B, int L, int H) { return lstm
 int mmqg_persist_launch_count(void) { return persist_launch_count(); }
 int64_t mmqg_lstm_seq_bwd_persist_ws_bytes(int T, int B, int L, int H) { return lstm_persist_bwd_ws_bytes(T, B, L, H); }
 int mmqg_persist_bwd_launch_count(void) { return persist_bwd_launch_count(); }
+int64_t mmqg_decoder_seq_persist_ws_bytes(const mmqg_decoder_seq* d) { return d ? decoder_persist_ws_bytes(*d) : 0; }
+int mmqg_decoder_persist_launch_count(void) { return decoder_persist_launch_count(); }
+int mmqg_decoder_persist_set_trace(uint64_t* buf, int64_t words) { decoder_persist_set_trace(reinterpret_cast<unsigned long long*>(buf), words); return 0; }
 int mmqg_persist_bwd_set_trace(uint64_t* buf, int64_t words) { persist_bwd_set_trace(reinterpret_cast<unsigned long long*>(buf), words); return 0; }
 int64_t mmqg_wide_ws_bytes(int B, int max_N) { return skinny_wide_ws_bytes(B, max_N); }
 int mmqg_persist_declined_count(void) { return persist_declined_count(); }

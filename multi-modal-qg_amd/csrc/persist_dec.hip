@@ -1,0 +1,557 @@
+// Persistent FORWARD time loop of the attention decoder (AttnDecoder.forward, model/decoder.py:74-107, driven one token
+// at a time by train.py:171-175): ONE launch runs all T teacher-forced steps.  A step is a strict chain — the scores
+// need h_top(t-1), the contexts need the scores, layer 0 needs the contexts, layer 1 needs layer 0, layer 2 needs layer
+// 1 — so there is no wavefront over (layer, time) as in the text encoder: the launch has FIVE phases per token, each
+// closed by the fence-free device-wide barrier of grid_barrier.h:
+//   S    scores(t) = hoisted half + h_top(t-1) W_attn[:, E:]^T      31 workgroups x 4 waves, one 16 x 16 MFMA tile each
+//   ATT  three softmaxes + three contexts (the 54 MB value stream)     every CU: 7 waves, one (question, modality,
+//                                                                       64-column chunk) item per wave (text items: two
+//                                                                       waves, rows halved, partials combined through LDS)
+//   L0   gates_0 = hoisted half + [ctx(t) | h_0(t-1)] [W_ih0c | W_hh0]^T -> cell     workgroups 0 .. H/4-1
+//   L1   [h_0(t) | h_1(t-1)] -> cell                                                  workgroups H/4 .. H/2-1
+//   L2   [h_1(t) | h_2(t-1)] -> cell                                                  the same workgroups
+// What the launches pay per token and this kernel does not: the recurrent weights (31 MB at config 2) stay in LDS for
+// the whole sequence — the attention's 54 MB per token flush the 32 MB of L2, so every layer-step LAUNCH re-fetches its
+// 8-13 MB of weights from the Infinity Cache — and the argument fetch / drain of five launches.  What it pays instead:
+// five barriers per token (2.3 us each + store acknowledgement + arrival skew) and only H/4 = 128 of the 256 CUs working
+// in a layer phase (an output-stationary unit of 16 gate columns x K <= 1664 is 64-106 KB: one or two per CU).
+// Exchange data (h of every layer, its dropped copy, the contexts, the scores) is stored write-through (sc1) and loaded
+// sc1, as in persist.hip; c and h of a unit's rows live in registers for the whole sequence.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "grid_barrier.h"
+#include "mmqg_common.h"
+#include "mmqg_kernels.h"
+
+namespace {
+
+using namespace mmqg;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kRows = 64;
+constexpr int kRing = 8;                 // operand chunks (1 KB per wave) in flight
+constexpr int kLdsBudget = 160 * 1024 - 1024;
+constexpr int kMaxSeg = 320;             // longest score segment an attention wave keeps in LDS (Lt = 283)
+
+struct DecArgs {
+    int T, B, H, E, Cw, S, ldS, G;
+    mmqg_attn_values v;
+    const float* pre_scores;             // [T][B][ldS] hoisted half of the scores (+ bias)
+    const float* w_attn_h; int ld_wa;    // score matrix rows s: w_attn_h + s * ld_wa (H floats): W_attn[:, E:]
+    const float* w_ih0c; int ld_w0;      // [4H] rows, Cw floats each: W_ih0[:, E:]
+    const float* w_hh0;                  // [4H][H]
+    const float* w_ih1; const float* w_hh1; const float* w_ih2; const float* w_hh2;
+    const float* b_ih1; const float* b_hh1; const float* b_ih2; const float* b_hh2;
+    const float* h0; const float* c0; int64_t h0_stride_l;
+    const int32_t* lens;
+    float* gates;                        // [3][T][B][4H]; layer 0's slots hold the hoisted pre-activations on entry
+    float* hs; float* cs;                // [3][T+1][B][H]
+    float* hdrop;                        // [2][T][B][H] or null
+    float* attn; float* ctx;             // [T][B][ldS], [T][B][Cw]
+    float drop_p; int drop; uint64_t seed, stream_base; const int32_t* seed_off;
+    // workspace: one buffer descriptor over hx | xd | cx | sx
+    float* hx;                           // [3][2][H/4][64][4]   h_l(t), slot t & 1
+    int xd_off, cx_off, sx_off, ex_bytes;   // byte offsets of xd [2][2][H/4][64][4], cx [Cw/4][64][4], sx [64][ldS]
+    gb::XBar* bar;
+    float* poison; unsigned* sticky_fail; unsigned* host_fail; unsigned expect_wg, max_spins;
+    unsigned long long* trace;
+};
+
+__device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const int32_t* off) {
+    return off ? seed + (uint64_t)(uint32_t)off[0] * 0x9E3779B97F4A7C15ull : seed;
+}
+
+template <typename Rsrc>
+__device__ __forceinline__ f32x4 ldx(const Rsrc& rs, int off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+}
+template <typename Rsrc>
+__device__ __forceinline__ void stx(const Rsrc& rs, int off, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 16);
+}
+
+__device__ __forceinline__ void mfma_chunk(f32x4& acc0, f32x4& acc1, const f32x4& wt, const f32x4& x) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt.x, x.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt.y, x.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt.z, x.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt.w, x.w, acc1, 0, 0, 0);
+}
+
+// One wave's share of a product: chunks [c_lo, c_lo + n) of 16 k each for ONE block of 16 rows.  Chunk c's operand
+// fragment sits at byte offset (c < hc ? off_x + c * cb : off_h + (c - hc) * cb) + lane_off, its weight fragment at
+// lds[wbase + c * 64 + lane].  n_pad (a multiple of kRing) pads the count with the all-zero weight chunk at LDS float4
+// index 0, so the loops are branch-free (hipcc then counts the outstanding loads instead of draining them).
+struct WaveProd { int n, n_pad, c_lo, hc, off_x, off_h, lane_off, wbase; };
+
+template <typename Rsrc>
+__device__ __forceinline__ f32x4 prod_load(const Rsrc& rs, const WaveProd& w, int i) {
+    constexpr int cb = 4 * kRows * 16;
+    const int c = w.c_lo + min(i, w.n - 1);
+    return ldx(rs, (c < w.hc ? w.off_x + c * cb : w.off_h + (c - w.hc) * cb) + w.lane_off);
+}
+__device__ __forceinline__ f32x4 prod_weight(const f32x4* lds, const WaveProd& w, int lane, int i) {
+    return lds[(i < w.n ? w.wbase + (w.c_lo + i) * 64 : 0) + lane];
+}
+template <typename Rsrc>
+__device__ __forceinline__ f32x4 wave_product(const Rsrc& rs, const WaveProd& w, const f32x4* lds, int lane) {
+    f32x4 ring[kRing];
+#pragma unroll
+    for (int d = 0; d < kRing; ++d) ring[d] = prod_load(rs, w, d);
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    f32x4 wcur = prod_weight(lds, w, lane, 0);
+    for (int i0 = 0; i0 + kRing < w.n_pad; i0 += kRing) {
+#pragma unroll
+        for (int d = 0; d < kRing; ++d) {
+            const f32x4 wnext = prod_weight(lds, w, lane, i0 + d + 1);
+            mfma_chunk(acc0, acc1, wcur, ring[d]);
+            ring[d] = prod_load(rs, w, i0 + kRing + d);
+            wcur = wnext;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < kRing; ++d) {
+        const f32x4 wnext = prod_weight(lds, w, lane, w.n_pad - kRing + min(d + 1, kRing - 1));
+        mfma_chunk(acc0, acc1, wcur, ring[d]);
+        wcur = wnext;
+    }
+    return acc0 + acc1;
+}
+
+#define MMQG_DSTAMP(slot)                                                                              \
+    if (TRACE && tid == 0) a.trace[((size_t)blockIdx.x * a.T + t) * 8 + (slot)] = wall_clock64();
+
+template <bool TRACE>
+__global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, B = a.B, H = a.H, Cw = a.Cw;
+    const int NU = H / 4;                          // units of 4 hidden units = 16 gate columns per layer
+    const int g = blockIdx.x;
+    const bool wg_l0 = g < NU, wg_l12 = g >= NU && g < 2 * NU;
+    const int unit = wg_l0 ? g : g - NU;
+    const int n_stile = (a.S + 15) / 16;
+    const bool wg_s = g < n_stile;
+    const int slot_f = kRows * H;                  // floats per (layer, slot) of hx / xd
+    const int nch0 = (Cw + H) / 16, nch12 = 2 * H / 16, nchs = H / 16;
+
+    // ---- LDS: [0,64) zero chunk | weight fragments | k-split partial tiles [8][64] | attention weights [7][kMaxSeg] floats
+    int wb0 = 64, wb1 = 64, wbs = 64, wtotal = 64;
+    if (wg_l0) { wb0 = wtotal; wtotal += nch0 * 64; }
+    if (wg_l12) { wb0 = wtotal; wtotal += nch12 * 64; wb1 = wtotal; wtotal += nch12 * 64; }
+    if (wg_s) { wbs = wtotal; wtotal += nchs * 64; }
+    f32x4* scratch = lds + wtotal;                                   // [kWaves][64]
+    float* att_e = reinterpret_cast<float*>(scratch + kWaves * 64);  // [7][kMaxSeg]
+    f32x4* att_comb = reinterpret_cast<f32x4*>(att_e + 7 * kMaxSeg); // [4][16] partial contexts of split text items
+    if (tid < 64) lds[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- weights -> LDS in fragment order: chunk c, lane (i = lane & 15: output column, kq = lane >> 4): 4 consecutive k
+    // of that output column's weight row.  Gate column i of a unit: weight row (i & 3) * H + 4 * unit + (i >> 2).
+    if (wg_l0) {
+        for (int idx = tid; idx < nch0 * 64; idx += kThreads) {
+            const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
+            const int row = (i & 3) * H + 4 * unit + (i >> 2), k = 16 * c + 4 * kq;
+            const float* src = k < Cw ? a.w_ih0c + (int64_t)row * a.ld_w0 + k : a.w_hh0 + (int64_t)row * H + (k - Cw);
+            lds[wb0 + idx] = *reinterpret_cast<const f32x4*>(src);
+        }
+    }
+    if (wg_l12) {
+        for (int idx = tid; idx < 2 * nch12 * 64; idx += kThreads) {
+            const int which = idx >= nch12 * 64, id2 = idx - which * nch12 * 64;
+            const int c = id2 >> 6, l = id2 & 63, i = l & 15, kq = l >> 4;
+            const int row = (i & 3) * H + 4 * unit + (i >> 2), k = 16 * c + 4 * kq;
+            const float* wi = which ? a.w_ih2 : a.w_ih1;
+            const float* wh = which ? a.w_hh2 : a.w_hh1;
+            const float* src = k < H ? wi + (int64_t)row * H + k : wh + (int64_t)row * H + (k - H);
+            lds[(which ? wb1 : wb0) + id2] = *reinterpret_cast<const f32x4*>(src);
+        }
+    }
+    if (wg_s) {
+        for (int idx = tid; idx < nchs * 64; idx += kThreads) {
+            const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
+            const int srow = min(16 * g + i, a.S - 1);
+            lds[wbs + idx] = *reinterpret_cast<const f32x4*>(a.w_attn_h + (int64_t)srow * a.ld_wa + 16 * c + 4 * kq);
+        }
+    }
+
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.hx, 0, a.ex_bytes, 0x00020000);
+
+    // ---- layer-phase roles: wave = (row block mb = wave & 3, k half ks = wave >> 2); the ks == 0 wave of a row block
+    // does the cell update: lane (j = lane & 15: row, q = lane >> 4: hidden unit 4 * unit + q) holds the four gates
+    const int j = lane & 15, q = lane >> 4;
+    const int mb = wave & 3, ks = wave >> 2;
+    const int row = mb * 16 + j;
+    const bool cellw = ks == 0;
+    const int lane_off = (q * kRows + row) * 16;
+    // state of (layer A, row, unit q) and, on the L1/L2 workgroups, of (layer 2, row, unit q)
+    float hA = 0.f, cA = 0.f, hB = 0.f, cB = 0.f;
+    float biasA[4] = {0.f, 0.f, 0.f, 0.f}, biasB[4] = {0.f, 0.f, 0.f, 0.f};
+    int len = T;
+    const int lA = wg_l0 ? 0 : 1;
+    if ((wg_l0 || wg_l12) && cellw) {
+        const int u = 4 * unit + q;
+        const int64_t hstr = a.h0_stride_l ? a.h0_stride_l : (int64_t)B * H;
+        if (row < B) {
+            hA = a.h0[lA * hstr + (int64_t)row * H + u]; cA = a.c0[lA * hstr + (int64_t)row * H + u];
+            if (wg_l12) { hB = a.h0[2 * hstr + (int64_t)row * H + u]; cB = a.c0[2 * hstr + (int64_t)row * H + u]; }
+            if (a.lens) len = a.lens[row];
+        }
+        if (wg_l12) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                biasA[r] = a.b_ih1[r * H + u] + a.b_hh1[r * H + u];
+                biasB[r] = a.b_ih2[r * H + u] + a.b_hh2[r * H + u];
+            }
+        }
+        // h(-1) of the layer(s) into slot 1 of the exchange buffer
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hA : 0.f), rs, ((lA * 2 + 1) * slot_f + (unit * kRows + row) * 4 + q) * 4, 0, 16);
+        if (wg_l12)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hB : 0.f), rs, ((2 * 2 + 1) * slot_f + (unit * kRows + row) * 4 + q) * 4, 0, 16);
+    }
+
+    // ---- attention-phase roles: waves 0-3 = two text items (two waves each: rows halved), waves 4-5 = two video items,
+    // wave 6 = one audio item (32 columns); item lists are question-major so that the batch's items spread over the CUs
+    const int chunks_t = (a.v.H + 63) / 64, chunks_v = (a.v.Dv + 63) / 64, chunks_a = (a.v.Da + 31) / 32;
+    const int n_text = B * chunks_t, n_video = B * chunks_v, n_audio = B * chunks_a;
+    const int text_rounds = (n_text + 2 * a.G - 1) / (2 * a.G), video_rounds = (n_video + 2 * a.G - 1) / (2 * a.G),
+              audio_rounds = (n_audio + a.G - 1) / a.G;
+    const int att_rounds = max(text_rounds, max(video_rounds, audio_rounds));
+
+    gb::Ctx bar;
+    bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
+    if (ok) ok = gb::sync(bar);
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    const uint64_t seed = a.drop ? eff_seed(a.seed, a.seed_off) : 0;
+
+    for (int t = 0; ok && t < T; ++t) {
+        MMQG_DSTAMP(0)
+        // =========================================================== S: scores(t) into sx
+        if (wg_s && wave < 4) {
+            WaveProd w;
+            w.n = nchs; w.n_pad = (nchs + kRing - 1) / kRing * kRing; w.c_lo = 0; w.hc = 0; w.off_x = 0;
+            w.off_h = ((2 * 2 + ((t - 1) & 1)) * slot_f) * 4;          // h_top(t-1)
+            w.lane_off = (q * kRows + wave * 16 + j) * 16; w.wbase = wbs;
+            const f32x4 acc = wave_product(rs, w, lds, lane);
+            const int b = wave * 16 + j, col = 16 * g + 4 * q;
+            if (b < B && col < a.ldS) {
+                const f32x4 pre = *reinterpret_cast<const f32x4*>(a.pre_scores + ((int64_t)t * B + b) * a.ldS + col);
+                stx(rs, a.sx_off + (b * a.ldS + col) * 4, acc + pre);
+            }
+        }
+        MMQG_DSTAMP(1)
+        ok = gb::sync(bar);
+        if (!ok) break;
+        MMQG_DSTAMP(2)
+        // =========================================================== ATT: softmax + contexts of step t
+        for (int rnd = 0; rnd < att_rounds; ++rnd) {
+            // this wave's item of the round
+            int modality = -1, item = 0, half = 0, nhalf = 1;
+            if (wave < 4) { item = (rnd * a.G + g) * 2 + (wave >> 1); half = wave & 1; nhalf = 2; if (item < n_text) modality = 0; }
+            else if (wave < 6) { item = (rnd * a.G + g) * 2 + (wave - 4); if (item < n_video) modality = 2; }
+            else if (wave == 6) { item = rnd * a.G + g; if (item < n_audio) modality = 1; }
+            f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+            float inv = 0.f;
+            int b = 0, chunk = 0, D = 0, L = 0, seg_off = 0, ctx_off = 0, col = 0;
+            bool col_ok = false;
+            float* e = att_e + min(wave, 6) * kMaxSeg;
+            if (modality >= 0) {
+                const int nchunks = modality == 0 ? chunks_t : (modality == 2 ? chunks_v : chunks_a);
+                const int cwidth = modality == 1 ? 32 : 64;
+                b = item / nchunks; chunk = item - b * nchunks;
+                const float* base; int valid;
+                if (modality == 0) { base = a.v.text + (int64_t)b * a.v.text_stride_b; L = a.v.Lt; D = a.v.H; seg_off = 0; ctx_off = 0; valid = a.v.text_len ? a.v.text_len[b] : L; }
+                else if (modality == 1) { base = a.v.audio + (int64_t)b * a.v.audio_stride_b; L = a.v.Lav; D = a.v.Da; seg_off = a.v.Lt; ctx_off = a.v.H; valid = a.v.av_len ? a.v.av_len[b] : L; }
+                else { base = a.v.video + (int64_t)b * a.v.video_stride_b; L = a.v.Lav; D = a.v.Dv; seg_off = a.v.Lt + a.v.Lav; ctx_off = a.v.H + a.v.Da; valid = a.v.av_len ? a.v.av_len[b] : L; }
+                const bool masked = a.v.mask_mode == MMQG_MASK_INTENDED;
+                const int n_stream = a.v.zero_past_len ? max(1, min(L, valid)) : L;
+                // rows of this wave: all, or its half
+                const int rows_half = (n_stream + nhalf - 1) / nhalf;
+                const int r_lo = half * rows_half, r_hi = min(n_stream, r_lo + rows_half);
+                const int lanes = cwidth / 4;                          // float4 column lanes (16, or 8 for audio)
+                const int groups = 64 / lanes;                         // row groups (4, or 8)
+                const int cl = lane % lanes, rgp = lane / lanes;
+                col = chunk * cwidth + 4 * cl;
+                col_ok = col < D;
+                const float* V = base + col;
+                // first loads of the value stream go out before the softmax
+                constexpr int kU = 8;
+                f32x4 cur[kU], nxt[kU];
+                const int last = max(r_hi - 1, r_lo);
+                auto fetch = [V, last, D, groups](f32x4 (&dst)[kU], int first) {
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) dst[u] = *reinterpret_cast<const f32x4*>(V + (int64_t)min(first + u * groups, last) * D);
+                };
+                const bool stream = col_ok && r_hi > r_lo;
+                if (stream) { fetch(cur, r_lo + rgp); fetch(nxt, r_lo + rgp + kU * groups); }
+                // softmax of the whole segment (both halves of a split item do it)
+                float lmax = -INFINITY;
+                for (int i = lane; i < L; i += 64) {
+                    float s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, a.sx_off + (b * a.ldS + seg_off + i) * 4, 0, 16));
+                    if (masked && i >= valid) s = -INFINITY;
+                    e[i] = s;
+                    lmax = fmaxf(lmax, s);
+                }
+                lmax = wave_max(lmax);
+                float lsum = 0.f;
+                for (int i = lane; i < L; i += 64) {
+                    const float x = expf(e[i] - lmax);
+                    e[i] = x;
+                    lsum += x;
+                }
+                lsum = wave_sum(lsum);
+                inv = 1.0f / lsum;
+                __builtin_amdgcn_wave_barrier();
+                if (chunk == 0 && half == 0) {
+                    float* arow = a.attn + ((int64_t)t * B + b) * a.ldS + seg_off;
+                    for (int i = lane; i < L; i += 64) arow[i] = e[i] * inv;
+                }
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                if (stream) {
+                    for (int r = r_lo + rgp; r < r_hi; r += kU * groups) {
+                        float wv[kU];
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) { const int i = r + u * groups; wv[u] = i < r_hi ? e[i] : 0.f; }
+#pragma unroll
+                        for (int u = 0; u < kU; u += 2) { acc0 += wv[u] * cur[u]; acc1 += wv[u + 1] * cur[u + 1]; }
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) cur[u] = nxt[u];
+                        if (r + 2 * kU * groups < r_hi) fetch(nxt, r + 2 * kU * groups);
+                    }
+                }
+                acc0 += acc1;
+                // combine the row groups of the wave (lanes with equal cl)
+                for (int off = lanes; off < 64; off <<= 1) {
+                    acc0.x += __shfl_xor(acc0.x, off, 64); acc0.y += __shfl_xor(acc0.y, off, 64);
+                    acc0.z += __shfl_xor(acc0.z, off, 64); acc0.w += __shfl_xor(acc0.w, off, 64);
+                }
+                part = acc0;
+                if (nhalf == 2 && half == 1 && lane < 16) att_comb[(wave >> 1) * 16 + lane] = part;
+            }
+            __syncthreads();                       // (every wave, with or without an item)
+            if (modality >= 0 && half == 0) {
+                const int lanes = modality == 1 ? 8 : 16;
+                if (lane < lanes && col_ok) {
+                    if (nhalf == 2) part += att_comb[(wave >> 1) * 16 + lane];
+                    part = part * inv;
+                    *reinterpret_cast<f32x4*>(a.ctx + ((int64_t)t * B + b) * Cw + ctx_off + col) = part;      // saved for backward
+                    stx(rs, a.cx_off + (((ctx_off + col) >> 2) * kRows + b) * 16, part);                        // operand of layer 0
+                }
+            }
+            __syncthreads();
+        }
+        MMQG_DSTAMP(3)
+        ok = gb::sync(bar);
+        if (!ok) break;
+        MMQG_DSTAMP(4)
+        // =========================================================== L0 / L1 / L2
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            const bool mine = ph == 0 ? wg_l0 : wg_l12;
+            float st_g[4] = {0.f, 0.f, 0.f, 0.f}, st_hd = 0.f;
+            bool st_on = false;
+            if (mine) {
+                const int l = ph;
+                const int nch = l == 0 ? nch0 : nch12;
+                WaveProd w;
+                const int per = (nch + 1) / 2;
+                w.c_lo = min(nch, ks * per);
+                w.n = min(nch, w.c_lo + per) - w.c_lo;
+                w.n_pad = (w.n + kRing - 1) / kRing * kRing;
+                w.hc = l == 0 ? Cw / 16 : H / 16;
+                w.off_x = l == 0 ? a.cx_off : ((a.drop ? a.xd_off : 0) + ((l - 1) * 2 + (t & 1)) * slot_f * 4);
+                w.off_h = (l * 2 + ((t - 1) & 1)) * slot_f * 4;
+                w.lane_off = lane_off;
+                w.wbase = l == 2 ? wb1 : wb0;
+                f32x4 pre4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (l == 0 && cellw && row < B) {
+                    const float* g0 = a.gates + ((int64_t)t * B + row) * 4 * H + 4 * unit + q;
+                    pre4 = f32x4{g0[0], g0[H], g0[2 * H], g0[3 * H]};
+                }
+                const f32x4 acc = wave_product(rs, w, lds, lane);
+                if (!cellw) scratch[wave * 64 + lane] = acc;
+                __syncthreads();
+                if (cellw) {
+                    f32x4 sum = acc + scratch[(wave + 4) * 64 + lane] + pre4;
+                    const int u = 4 * unit + q;
+                    const bool valid = row < B, active = valid && t < len;
+                    float& hreg = l == 2 ? hB : hA;
+                    float& creg = l == 2 ? cB : cA;
+                    const float* bias = l == 2 ? biasB : biasA;
+                    const float gi = sigmoidf_(sum.x + bias[0]), gf = sigmoidf_(sum.y + bias[1]);
+                    const float gg = tanhf(sum.z + bias[2]), go = sigmoidf_(sum.w + bias[3]);
+                    if (active) { creg = gf * creg + gi * gg; hreg = go * tanhf(creg); }
+                    float hd = 0.f;
+                    const bool to_above = l < 2;
+                    if (a.drop && to_above && active)
+                        hd = hreg * dropout_scale(seed, a.stream_base + (uint64_t)l * T + t, (uint64_t)((int64_t)row * H + u), a.drop_p);
+                    const int xoff = ((l * 2 + (t & 1)) * slot_f) * 4 + ((unit * kRows + row) * 4) * 4;
+                    {
+                        const float hv = valid ? hreg : 0.f;
+                        const f32x4 pk = f32x4{hv, __shfl(hv, j + 16, 64), __shfl(hv, j + 32, 64), __shfl(hv, j + 48, 64)};
+                        if (q == 0) stx(rs, xoff, pk);
+                    }
+                    if (a.drop && to_above) {
+                        const f32x4 pk = f32x4{hd, __shfl(hd, j + 16, 64), __shfl(hd, j + 32, 64), __shfl(hd, j + 48, 64)};
+                        if (q == 0) stx(rs, a.xd_off + xoff, pk);
+                    }
+                    st_g[0] = active ? gi : 0.f; st_g[1] = active ? gf : 0.f; st_g[2] = active ? gg : 0.f; st_g[3] = active ? go : 0.f;
+                    st_hd = hd; st_on = valid;
+                }
+            } else {
+                __syncthreads();
+            }
+            MMQG_DSTAMP(5 + ph)
+            gb::arrive(bar);
+            // saved activations (only later kernels read them): behind the arrival
+            if (mine && cellw && st_on) {
+                const int l = ph, u = 4 * unit + q;
+                float* grow = a.gates + (((int64_t)l * T + t) * B + row) * 4 * H + u;
+                grow[0] = st_g[0]; grow[H] = st_g[1]; grow[2 * H] = st_g[2]; grow[3 * H] = st_g[3];
+                const int64_t e = (((int64_t)l * (T + 1) + t + 1) * B + row) * H + u;
+                a.hs[e] = l == 2 ? hB : hA; a.cs[e] = l == 2 ? cB : cA;
+                if (a.drop && l < 2) a.hdrop[(((int64_t)l * T + t) * B + row) * H + u] = st_hd;
+            }
+            ok = gb::wait(bar);
+            if (!ok) break;
+        }
+    }
+    if (!ok) {
+        gb::report_failure(a.sticky_fail, a.host_fail);
+        if (tid == 0) a.poison[0] = __builtin_nanf("");
+    }
+}
+#undef MMQG_DSTAMP
+
+inline int64_t align_up(int64_t v, int64_t al) { return (v + al - 1) / al * al; }
+
+struct WsLayout { int64_t bar, hx, xd, cx, sx, sticky, total; };
+WsLayout ws_layout(int H, int Cw, int ldS) {
+    WsLayout w;
+    w.bar = 0;
+    w.hx = align_up((int64_t)sizeof(gb::XBar), 256);
+    w.xd = w.hx + (int64_t)3 * 2 * kRows * H * 4;
+    w.cx = w.xd + (int64_t)2 * 2 * kRows * H * 4;
+    w.sx = w.cx + (int64_t)kRows * Cw * 4;
+    w.sticky = align_up(w.sx + (int64_t)kRows * ldS * 4, 256);
+    w.total = w.sticky + 256;
+    return w;
+}
+
+int lds_need(int H, int Cw) {
+    const int l0 = ((Cw + H) / 16 + H / 16) * 1024;             // layer-0 unit + a score tile
+    const int l12 = 2 * (2 * H / 16) * 1024;
+    return 1024 + std::max(l0, l12) + kWaves * 1024 + 7 * kMaxSeg * 4 + 4 * 16 * 16;
+}
+
+}  // namespace
+
+namespace mmqg {
+
+static int g_dec_persist_launches = 0;
+int decoder_persist_launch_count() { return g_dec_persist_launches; }
+static unsigned long long* g_dtrace_buf = nullptr;
+static int64_t g_dtrace_words = 0;
+void decoder_persist_set_trace(unsigned long long* buf, int64_t words) { g_dtrace_buf = buf; g_dtrace_words = buf ? words : 0; }
+
+bool decoder_persist_shape_ok(const mmqg_decoder_seq& d) {
+    static const bool on = [] { const char* e = getenv("MMQG_PERSIST_DEC"); return e && atoi(e) != 0; }();
+    if (!on) return false;
+    const mmqg_attn_values& v = d.values;
+    const int H = d.H, Cw = v.H + v.Da + v.Dv, S = v.Lt + 2 * v.Lav;
+    if (d.L != 3 || d.T < 2 || d.B < 1 || d.B > kRows) return false;
+    if (H % 16 || Cw % 16 || v.H != H || v.H % 4 || v.Da % 4 || v.Dv % 4 || d.E % 4 || d.ld_attn % 4) return false;
+    if (v.Lt > kMaxSeg || v.Lav > kMaxSeg) return false;
+    if ((S + 15) / 16 > H / 4) return false;
+    return lds_need(H, Cw) <= kLdsBudget;
+}
+
+int64_t decoder_persist_ws_bytes(const mmqg_decoder_seq& d) {
+    if (!decoder_persist_shape_ok(d)) return 0;
+    persist_runtime_prepare();
+    const mmqg_attn_values& v = d.values;
+    return ws_layout(d.H, v.H + v.Da + v.Dv, d.ld_attn).total;
+}
+
+// 0 = done (the whole time loop), 1 = not taken, < 0 = error
+int decoder_seq_fwd_persistent(const mmqg_decoder_seq& d, hipStream_t s) {
+    if (!d.persist_ws || !decoder_persist_shape_ok(d)) return 1;
+    const mmqg_attn_values& v = d.values;
+    const int T = d.T, B = d.B, H = d.H, E = d.E, Cw = v.H + v.Da + v.Dv, S = v.Lt + 2 * v.Lav;
+    const WsLayout wl = ws_layout(H, Cw, d.ld_attn);
+    if (d.persist_ws_bytes < wl.total || !aligned16(d.persist_ws)) return 1;
+    const int G = std::min(persist_device_cus(), 256);
+    if (G < 2 * (H / 4)) return 1;
+    const bool drop = d.training && d.dropout_p > 0.f;
+    if (drop && !d.hdrop) return 1;
+    const float* ptrs[] = {d.w_attn, d.w_ih[0], d.w_hh[0], d.w_ih[1], d.w_hh[1], d.w_ih[2], d.w_hh[2], d.scores, d.ctx, d.gates,
+                           v.text, v.audio, v.video};
+    for (const float* p : ptrs) if (!p || !aligned16(p)) return 1;
+    if ((E + H) % 4 || (E + Cw) % 4 || v.text_stride_b % 4 || v.audio_stride_b % 4 || v.video_stride_b % 4) return 1;
+    if ((v.mask_mode == MMQG_MASK_INTENDED || v.zero_past_len) && !(v.text_len && v.av_len)) return 1;
+    const int lds_bytes = lds_need(H, Cw);
+    static int attr_set = 0;
+    if (attr_set == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_persist_fwd_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_persist_fwd_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+        if (e != hipSuccess) (void)hipGetLastError();
+        attr_set = e == hipSuccess ? 1 : -1;
+    }
+    if (attr_set < 0) return 1;
+    {
+        static int occ_lds = -1, occ_ok = 0;
+        if (occ_lds != lds_bytes) {
+            int nb = 0;
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &nb, reinterpret_cast<const void*>(decoder_persist_fwd_kernel<false>), kThreads, (size_t)lds_bytes);
+            if (e != hipSuccess) (void)hipGetLastError();
+            occ_lds = lds_bytes; occ_ok = (e == hipSuccess && nb >= 1) ? 1 : 0;
+        }
+        if (!occ_ok) return 1;
+    }
+    if (persist_begin(s) != 0) return 1;
+
+    char* ws = reinterpret_cast<char*>(d.persist_ws);
+    const int64_t BH = (int64_t)B * H;
+    // (slot 0 of hs / cs already holds the initial state: decoder_seq_fwd) the barrier block and the exchange buffers
+    // start from zero
+    const CopySeg init{reinterpret_cast<float*>(ws), nullptr, wl.sticky / 4};
+    MMQG_TRY(copy_or_zero_multi(&init, 1, s));
+    DecArgs a{};
+    a.T = T; a.B = B; a.H = H; a.E = E; a.Cw = Cw; a.S = S; a.ldS = d.ld_attn; a.G = G;
+    a.v = v;
+    a.pre_scores = d.scores;
+    a.w_attn_h = d.w_attn + E; a.ld_wa = E + H;
+    a.w_ih0c = d.w_ih[0] + E; a.ld_w0 = E + Cw; a.w_hh0 = d.w_hh[0];
+    a.w_ih1 = d.w_ih[1]; a.w_hh1 = d.w_hh[1]; a.w_ih2 = d.w_ih[2]; a.w_hh2 = d.w_hh[2];
+    a.b_ih1 = d.b_ih[1]; a.b_hh1 = d.b_hh[1]; a.b_ih2 = d.b_ih[2]; a.b_hh2 = d.b_hh[2];
+    a.h0 = d.h0; a.c0 = d.c0; a.h0_stride_l = d.h0_stride_l; a.lens = d.lens;
+    a.gates = d.gates; a.hs = d.hs; a.cs = d.cs; a.hdrop = d.hdrop; a.attn = d.attn; a.ctx = d.ctx;
+    a.drop = drop ? 1 : 0; a.drop_p = drop ? d.dropout_p : 0.f; a.seed = d.seed; a.stream_base = d.stream_base; a.seed_off = d.seed_offset;
+    a.hx = reinterpret_cast<float*>(ws + wl.hx);
+    a.xd_off = (int)(wl.xd - wl.hx); a.cx_off = (int)(wl.cx - wl.hx); a.sx_off = (int)(wl.sx - wl.hx);
+    a.ex_bytes = (int)(wl.sticky - wl.hx);
+    a.bar = reinterpret_cast<gb::XBar*>(ws + wl.bar);
+    a.poison = d.hs + ((int64_t)2 * (T + 1) + T) * BH;
+    a.sticky_fail = reinterpret_cast<unsigned*>(ws + wl.sticky);
+    a.host_fail = persist_host_fail_word();
+    a.expect_wg = (unsigned)(G + persist_test_extra_wg());
+    a.max_spins = persist_test_max_spins() ? persist_test_max_spins() : gb::kDefaultSpins;
+    a.trace = nullptr;
+    if (g_dtrace_buf && (int64_t)G * T * 8 <= g_dtrace_words) a.trace = g_dtrace_buf;
+    if (a.trace) hipLaunchKernelGGL(decoder_persist_fwd_kernel<true>, dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
+    else hipLaunchKernelGGL(decoder_persist_fwd_kernel<false>, dim3(G), dim3(kThreads), (size_t)lds_bytes, s, a);
+    g_dec_persist_launches += 1;
+    persist_end(s);
+    return check_launch("decoder_persist_fwd");
+}
+
+}  // namespace mmqg

@@ -430,6 +430,10 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
                           d.b_ih[0], d.b_hh[0], 0, d.gates, 4 * H, -1, s));
     }
     if (d.phase == 1) return 0;
+    if (d.persist_ws && !g_no_fuse()) {      // the whole time loop as one persistent launch (persist_dec.hip; opt-in)
+        const int rc = decoder_seq_fwd_persistent(d, s);
+        if (rc <= 0) return rc;
+    }
     const float* htop_base = d.hs + (int64_t)(L - 1) * (T + 1) * BH;
     // Look-ahead (as in the backward loop): the recurrent half of a layer-step, h_l(t) W_hh_l^T, only needs h_l(t), which
     // exists one launch after cell (l, t) — a whole token before cell (l, t+1) uses it.  It is formed as an extra plain job

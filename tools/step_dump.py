@@ -53,6 +53,7 @@ def main():
         out["grad_" + name] = g[lo:hi]
     out["persist_launches"] = np.int64(_lib.load().mmqg_persist_launch_count())
     out["persist_bwd_launches"] = np.int64(_lib.load().mmqg_persist_bwd_launch_count())
+    out["decoder_persist_launches"] = np.int64(_lib.load().mmqg_decoder_persist_launch_count())
     out["projection_kernel"] = np.int64(_lib.load().mmqg_projection_last_kernel())
     np.savez(a.out, **out)
     print(f"step_dump: {w.name.split(':')[0]} B={B} loss {loss:.6f} -> {a.out}")
