@@ -254,7 +254,8 @@ def loop_rooflines(tr, w):
                      "frac_of_fp32_mfma_peak": round(flop / per / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                      "distinct_operand_bytes_per_" + unit: int(nbytes), "achieved_gbs": round(nbytes / per / 1e9, 1),
                      "frac_of_hbm_peak": round(nbytes / per / 1e9 / HBM_PEAK_GBS, 4), "bound": "latency: " + stages}
-    out["persistent_launches"] = {"forward": int(lib.mmqg_persist_launch_count()), "backward": int(lib.mmqg_persist_bwd_launch_count())}
+    out["persistent_launches"] = {"forward": int(lib.mmqg_persist_launch_count()), "backward": int(lib.mmqg_persist_bwd_launch_count()),
+                                  "decoder_forward": int(lib.mmqg_decoder_persist_launch_count())}
     return out
 
 

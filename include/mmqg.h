@@ -346,7 +346,7 @@ typedef struct {
                                                        as ONE launch (mmqg_attn_scores_softmax_context_fwd) */
     float* persist_ws; int64_t persist_ws_bytes;    /* optional workspace (mmqg_decoder_seq_persist_ws_bytes): the whole
                                                        time loop then runs as ONE persistent launch when the shape is
-                                                       taken (opt-in: MMQG_PERSIST_DEC=1) */
+                                                       taken (MMQG_NO_PERSIST_DEC=1 / MMQG_NO_PERSIST=1: never) */
 } mmqg_decoder_seq;
 
 typedef struct {
@@ -409,7 +409,8 @@ int mmqg_sample_gumbel(const float* logits, int ld, int rows, int V, uint64_t se
 
 int mmqg_decoder_seq_fwd(const mmqg_decoder_seq* d, mmqg_stream stream);
 /* bytes of mmqg_decoder_seq.persist_ws for this descriptor (T, B, L, H, E, values, ld_attn are read); 0 = the shape is
- * not taken or MMQG_PERSIST_DEC is not set: the time loop then runs five launches per token */
+ * not taken (B > 64, L != 3, weights beyond the chip's LDS, ...) or MMQG_NO_PERSIST_DEC=1: the time loop then runs five
+ * launches per token */
 int64_t mmqg_decoder_seq_persist_ws_bytes(const mmqg_decoder_seq* d);
 /* diagnostics, as mmqg_persist_launch_count / mmqg_persist_set_trace (8 stamps per (workgroup, token): start, scores
  * stored, barrier passed, contexts stored, barrier passed, layer 0 / 1 / 2 arrived) */

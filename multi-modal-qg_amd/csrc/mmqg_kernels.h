@@ -161,7 +161,7 @@ int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g,
                             const mmqg_lstm_seq_grad* g2, hipStream_t s);
 int persist_bwd_launch_count();
 void persist_bwd_set_trace(unsigned long long* buf, int64_t words);
-// persist_dec.hip: the forward time loop of the attention decoder as one persistent launch (opt-in)
+// persist_dec.hip: the forward time loop of the attention decoder as one persistent launch
 bool decoder_persist_shape_ok(const mmqg_decoder_seq& d);
 int64_t decoder_persist_ws_bytes(const mmqg_decoder_seq& d);
 int decoder_seq_fwd_persistent(const mmqg_decoder_seq& d, hipStream_t s);   // 0 done, 1 not taken, < 0 error

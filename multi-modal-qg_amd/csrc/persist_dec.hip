@@ -35,7 +35,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 512;
 constexpr int kWaves = kThreads / 64;
 constexpr int kRows = 64;
-constexpr int kRing = 8;                 // operand chunks (1 KB per wave) in flight
+constexpr int kRingAhead = 16;           // operand chunks (1 KB per wave) in flight: products in idle windows
+constexpr int kRingLate = 16;             // ... products on the chain (layer 0: 12)
 constexpr int kLdsBudget = 160 * 1024 - 1024;
 constexpr int kMaxSeg = 320;             // longest score segment an attention wave keeps in LDS (Lt = 283)
 
@@ -56,8 +57,8 @@ struct DecArgs {
     float* attn; float* ctx;             // [T][B][ldS], [T][B][Cw]
     float drop_p; int drop; uint64_t seed, stream_base; const int32_t* seed_off;
     // workspace: one buffer descriptor over hx | xd | cx | sx
-    float* hx;                           // [3][2][H/4][64][4]   h_l(t), slot t & 1
-    int xd_off, cx_off, sx_off, ex_bytes;   // byte offsets of xd [2][2][H/4][64][4], cx [Cw/4][64][4], sx [64][ldS]
+    float* hx;                           // [3][T+1][H/4][64][4]   h_l(t) in slot t + 1
+    int xd_off, cx_off, sx_off, ex_bytes;   // byte offsets of xd [2][T][H/4][64][4], cx [T][Cw/4][64][4], sx [T][64][ldS]
     gb::XBar* bar;
     float* poison; unsigned* sticky_fail; unsigned* host_fail; unsigned expect_wg, max_spins;
     unsigned long long* trace;
@@ -69,7 +70,7 @@ __device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const int32_t* off) 
 
 template <typename Rsrc>
 __device__ __forceinline__ f32x4 ldx(const Rsrc& rs, int off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
 }
 template <typename Rsrc>
 __device__ __forceinline__ void stx(const Rsrc& rs, int off, const f32x4& v) {
@@ -83,40 +84,46 @@ __device__ __forceinline__ void mfma_chunk(f32x4& acc0, f32x4& acc1, const f32x4
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wt.w, x.w, acc1, 0, 0, 0);
 }
 
-// One wave's share of a product: chunks [c_lo, c_lo + n) of 16 k each for ONE block of 16 rows.  Chunk c's operand
-// fragment sits at byte offset (c < hc ? off_x + c * cb : off_h + (c - hc) * cb) + lane_off, its weight fragment at
-// lds[wbase + c * 64 + lane].  n_pad (a multiple of kRing) pads the count with the all-zero weight chunk at LDS float4
-// index 0, so the loops are branch-free (hipcc then counts the outstanding loads instead of draining them).
-struct WaveProd { int n, n_pad, c_lo, hc, off_x, off_h, lane_off, wbase; };
+// One wave's share of a product: n chunks of 16 k each for ONE block of 16 rows.  Chunk i's operand fragment sits at byte
+// offset off + i * (4 * 64 * 16) of the exchange buffer (off includes the lane's share), its weight fragment at
+// lds[wbase + i * 64 + lane].  The count is padded to a multiple of the ring depth R with the all-zero weight chunk at
+// LDS float4 index 0, so the loops are branch-free (hipcc then counts the outstanding loads instead of draining them).
+struct WaveProd { int n, off, wbase; };
 
-template <typename Rsrc>
-__device__ __forceinline__ f32x4 prod_load(const Rsrc& rs, const WaveProd& w, int i) {
+__device__ __forceinline__ WaveProd make_prod(int n_total, int part, int nparts, int off0, int wbase0, int lane_off) {
+    const int per = (n_total + nparts - 1) / nparts;
+    const int lo = min(n_total, part * per);
+    WaveProd w;
+    w.n = max(1, min(n_total, lo + per) - lo);
+    w.off = off0 + lo * (4 * kRows * 16) + lane_off;
+    w.wbase = wbase0 + lo * 64;
+    return w;
+}
+
+// (not inlined: seven call sites; inlined, hipcc runs the kernel out of registers — 54 spilled — at R = 16)
+template <int R, typename Rsrc>
+__device__ __attribute__((noinline)) f32x4 wave_product(const Rsrc rs, const WaveProd w, const f32x4* lds, int lane) {
     constexpr int cb = 4 * kRows * 16;
-    const int c = w.c_lo + min(i, w.n - 1);
-    return ldx(rs, (c < w.hc ? w.off_x + c * cb : w.off_h + (c - w.hc) * cb) + w.lane_off);
-}
-__device__ __forceinline__ f32x4 prod_weight(const f32x4* lds, const WaveProd& w, int lane, int i) {
-    return lds[(i < w.n ? w.wbase + (w.c_lo + i) * 64 : 0) + lane];
-}
-template <typename Rsrc>
-__device__ __forceinline__ f32x4 wave_product(const Rsrc& rs, const WaveProd& w, const f32x4* lds, int lane) {
-    f32x4 ring[kRing];
+    const int n_pad = (w.n + R - 1) / R * R;
+    f32x4 ring[R];
 #pragma unroll
-    for (int d = 0; d < kRing; ++d) ring[d] = prod_load(rs, w, d);
+    for (int d = 0; d < R; ++d) ring[d] = ldx(rs, w.off + min(d, w.n - 1) * cb);
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    f32x4 wcur = prod_weight(lds, w, lane, 0);
-    for (int i0 = 0; i0 + kRing < w.n_pad; i0 += kRing) {
+    f32x4 wcur = lds[w.wbase + lane];
+    for (int i0 = 0; i0 + R < n_pad; i0 += R) {
 #pragma unroll
-        for (int d = 0; d < kRing; ++d) {
-            const f32x4 wnext = prod_weight(lds, w, lane, i0 + d + 1);
+        for (int d = 0; d < R; ++d) {
+            const int in = i0 + d + 1;
+            const f32x4 wnext = lds[(in < w.n ? w.wbase + in * 64 : 0) + lane];
             mfma_chunk(acc0, acc1, wcur, ring[d]);
-            ring[d] = prod_load(rs, w, i0 + kRing + d);
+            ring[d] = ldx(rs, w.off + min(i0 + R + d, w.n - 1) * cb);
             wcur = wnext;
         }
     }
 #pragma unroll
-    for (int d = 0; d < kRing; ++d) {
-        const f32x4 wnext = prod_weight(lds, w, lane, w.n_pad - kRing + min(d + 1, kRing - 1));
+    for (int d = 0; d < R; ++d) {
+        const int in = n_pad - R + min(d + 1, R - 1);
+        const f32x4 wnext = lds[(in < w.n ? w.wbase + in * 64 : 0) + lane];
         mfma_chunk(acc0, acc1, wcur, ring[d]);
         wcur = wnext;
     }
@@ -138,7 +145,15 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
     const int unit = wg_l0 ? g : g - NU;
     const int n_stile = (a.S + 15) / 16;
     const bool wg_s = g < n_stile;
-    const int slot_f = kRows * H;                  // floats per (layer, slot) of hx / xd
+    const int slot_f = kRows * H;                  // floats per (layer, token) slot of hx / xd
+    // Every (layer, token) has its OWN slot in the exchange buffers: a line is written once (write-through) and only read
+    // after the barrier behind its production, so no cache on the chip can hold an older copy of it — the loads are
+    // plain cached loads, and the 16 workgroups of an XCD that all need the same h fetch it once from the fabric and 15
+    // times from their L2 (with two alternating slots the loads had to bypass the L2s: 16 MB over the fabric per phase).
+    auto hoff = [=](int l, int t) { return (l * (T + 1) + t + 1) * slot_f * 4; };           // h_l(t); t = -1: the initial state
+    auto xdoff = [=](int l, int t) { return a.xd_off + (l * T + t) * slot_f * 4; };         // dropped copy of h_l(t), l < 2
+    auto cxoff = [=](int t) { return a.cx_off + t * kRows * Cw * 4; };
+    auto sxoff = [=](int t) { return a.sx_off + t * kRows * a.ldS * 4; };
     const int nch0 = (Cw + H) / 16, nch12 = 2 * H / 16, nchs = H / 16;
 
     // ---- LDS: [0,64) zero chunk | weight fragments | k-split partial tiles [8][64] | attention weights [7][kMaxSeg] floats
@@ -182,12 +197,13 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
 
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.hx, 0, a.ex_bytes, 0x00020000);
 
-    // ---- layer-phase roles: wave = (row block mb = wave & 3, k half ks = wave >> 2); the ks == 0 wave of a row block
-    // does the cell update: lane (j = lane & 15: row, q = lane >> 4: hidden unit 4 * unit + q) holds the four gates
+    // ---- layer-phase roles: wave = (row block mb = wave & 3, k half ks = wave >> 2); the ks == 1 wave of a row block
+    // (waves 4-7: thread 0, which polls the barrier, is in none of them) keeps the recurrent half of its product, formed
+    // ahead in an idle window, in registers and does the cell update: lane (j = lane & 15: row, q = lane >> 4: hidden unit 4 * unit + q) holds the four gates
     const int j = lane & 15, q = lane >> 4;
     const int mb = wave & 3, ks = wave >> 2;
     const int row = mb * 16 + j;
-    const bool cellw = ks == 0;
+    const bool cellw = ks == 1;
     const int lane_off = (q * kRows + row) * 16;
     // state of (layer A, row, unit q) and, on the L1/L2 workgroups, of (layer 2, row, unit q)
     float hA = 0.f, cA = 0.f, hB = 0.f, cB = 0.f;
@@ -210,9 +226,9 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
             }
         }
         // h(-1) of the layer(s) into slot 1 of the exchange buffer
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hA : 0.f), rs, ((lA * 2 + 1) * slot_f + (unit * kRows + row) * 4 + q) * 4, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hA : 0.f), rs, hoff(lA, -1) + ((unit * kRows + row) * 4 + q) * 4, 0, 16);
         if (wg_l12)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hB : 0.f), rs, ((2 * 2 + 1) * slot_f + (unit * kRows + row) * 4 + q) * 4, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hB : 0.f), rs, hoff(2, -1) + ((unit * kRows + row) * 4 + q) * 4, 0, 16);
     }
 
     // ---- attention-phase roles: waves 0-3 = two text items (two waves each: rows halved), waves 4-5 = two video items,
@@ -226,26 +242,31 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
     gb::Ctx bar;
     bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
     if (ok) ok = gb::sync(bar);
+    f32x4 aheadA = f32x4{0.f, 0.f, 0.f, 0.f}, aheadB = aheadA;
+    if (ok && wg_l0 && cellw)          // token 0 of layer 0: h_0(-1) W_hh0^T
+        aheadA = wave_product<kRingAhead>(rs, make_prod(H / 16, 0, 1, hoff(0, -1), wb0 + (Cw / 16) * 64, lane_off), lds, lane);
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const uint64_t seed = a.drop ? eff_seed(a.seed, a.seed_off) : 0;
 
     for (int t = 0; ok && t < T; ++t) {
         MMQG_DSTAMP(0)
         // =========================================================== S: scores(t) into sx
-        if (wg_s && wave < 4) {
-            WaveProd w;
-            w.n = nchs; w.n_pad = (nchs + kRing - 1) / kRing * kRing; w.c_lo = 0; w.hc = 0; w.off_x = 0;
-            w.off_h = ((2 * 2 + ((t - 1) & 1)) * slot_f) * 4;          // h_top(t-1)
-            w.lane_off = (q * kRows + wave * 16 + j) * 16; w.wbase = wbs;
-            const f32x4 acc = wave_product(rs, w, lds, lane);
-            const int b = wave * 16 + j, col = 16 * g + 4 * q;
-            if (b < B && col < a.ldS) {
-                const f32x4 pre = *reinterpret_cast<const f32x4*>(a.pre_scores + ((int64_t)t * B + b) * a.ldS + col);
-                stx(rs, a.sx_off + (b * a.ldS + col) * 4, acc + pre);
-            }
+        if (wg_s) {
+            const int b = mb * 16 + j, col = 16 * g + 4 * q;
+            const bool st = cellw && b < B && col < a.ldS;
+            f32x4 pre = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (st) pre = *reinterpret_cast<const f32x4*>(a.pre_scores + ((int64_t)t * B + b) * a.ldS + col);
+            const WaveProd w = make_prod(nchs, ks, 2, hoff(2, t - 1), wbs, lane_off);      // h_top(t-1)
+            const f32x4 acc = wave_product<kRingLate>(rs, w, lds, lane);
+            if (!cellw) scratch[wave * 64 + lane] = acc;
+            __syncthreads();
+            if (st) stx(rs, sxoff(t) + (b * a.ldS + col) * 4, acc + scratch[(wave - 4) * 64 + lane] + pre);
         }
         MMQG_DSTAMP(1)
-        ok = gb::sync(bar);
+        gb::arrive(bar);
+        // idle window of the layer-1/2 workgroups: the recurrent half of layer 2's product, h_2(t-1) W_hh2^T
+        if (wg_l12 && cellw) aheadB = wave_product<kRingAhead>(rs, make_prod(H / 16, 0, 1, hoff(2, t - 1), wb1 + (H / 16) * 64, lane_off), lds, lane);
+        ok = gb::wait(bar);
         if (!ok) break;
         MMQG_DSTAMP(2)
         // =========================================================== ATT: softmax + contexts of step t
@@ -278,21 +299,24 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
                 const int cl = lane % lanes, rgp = lane / lanes;
                 col = chunk * cwidth + 4 * cl;
                 col_ok = col < D;
-                const float* V = base + col;
+                // the question's value rows through a buffer descriptor: one 32-bit offset per load instead of a 64-bit address
+                const auto rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, L * D * 4, 0x00020000);
+                const int coff = col * 4, rowb = D * 4;
                 // first loads of the value stream go out before the softmax
                 constexpr int kU = 8;
                 f32x4 cur[kU], nxt[kU];
                 const int last = max(r_hi - 1, r_lo);
-                auto fetch = [V, last, D, groups](f32x4 (&dst)[kU], int first) {
+                auto fetch = [&rv, coff, rowb, last, groups](f32x4 (&dst)[kU], int first) {
 #pragma unroll
-                    for (int u = 0; u < kU; ++u) dst[u] = *reinterpret_cast<const f32x4*>(V + (int64_t)min(first + u * groups, last) * D);
+                    for (int u = 0; u < kU; ++u)
+                        dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, coff + min(first + u * groups, last) * rowb, 0, 0));
                 };
                 const bool stream = col_ok && r_hi > r_lo;
                 if (stream) { fetch(cur, r_lo + rgp); fetch(nxt, r_lo + rgp + kU * groups); }
                 // softmax of the whole segment (both halves of a split item do it)
                 float lmax = -INFINITY;
                 for (int i = lane; i < L; i += 64) {
-                    float s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, a.sx_off + (b * a.ldS + seg_off + i) * 4, 0, 16));
+                    float s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, sxoff(t) + (b * a.ldS + seg_off + i) * 4, 0, 0));
                     if (masked && i >= valid) s = -INFINITY;
                     e[i] = s;
                     lmax = fmaxf(lmax, s);
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
                     if (nhalf == 2) part += att_comb[(wave >> 1) * 16 + lane];
                     part = part * inv;
                     *reinterpret_cast<f32x4*>(a.ctx + ((int64_t)t * B + b) * Cw + ctx_off + col) = part;      // saved for backward
-                    stx(rs, a.cx_off + (((ctx_off + col) >> 2) * kRows + b) * 16, part);                        // operand of layer 0
+                    stx(rs, cxoff(t) + (((ctx_off + col) >> 2) * kRows + b) * 16, part);                        // operand of layer 0
                 }
             }
             __syncthreads();
@@ -356,28 +380,23 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
             float st_g[4] = {0.f, 0.f, 0.f, 0.f}, st_hd = 0.f;
             bool st_on = false;
             if (mine) {
+                // the late half of the product (layer 0: the contexts; layers 1, 2: the layer below), k-split over the two
+                // waves of a row block
                 const int l = ph;
-                const int nch = l == 0 ? nch0 : nch12;
-                WaveProd w;
-                const int per = (nch + 1) / 2;
-                w.c_lo = min(nch, ks * per);
-                w.n = min(nch, w.c_lo + per) - w.c_lo;
-                w.n_pad = (w.n + kRing - 1) / kRing * kRing;
-                w.hc = l == 0 ? Cw / 16 : H / 16;
-                w.off_x = l == 0 ? a.cx_off : ((a.drop ? a.xd_off : 0) + ((l - 1) * 2 + (t & 1)) * slot_f * 4);
-                w.off_h = (l * 2 + ((t - 1) & 1)) * slot_f * 4;
-                w.lane_off = lane_off;
-                w.wbase = l == 2 ? wb1 : wb0;
+                const int off_x = l == 0 ? cxoff(t) : (a.drop ? xdoff(l - 1, t) : hoff(l - 1, t));
+                const int wbase = l == 2 ? wb1 : wb0;
                 f32x4 pre4 = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (l == 0 && cellw && row < B) {
                     const float* g0 = a.gates + ((int64_t)t * B + row) * 4 * H + 4 * unit + q;
                     pre4 = f32x4{g0[0], g0[H], g0[2 * H], g0[3 * H]};
                 }
-                const f32x4 acc = wave_product(rs, w, lds, lane);
+                f32x4 acc;
+                if (l == 0) acc = wave_product<12>(rs, make_prod(Cw / 16, ks, 2, off_x, wbase, lane_off), lds, lane);
+                else acc = wave_product<kRingLate>(rs, make_prod(H / 16, ks, 2, off_x, wbase, lane_off), lds, lane);
                 if (!cellw) scratch[wave * 64 + lane] = acc;
                 __syncthreads();
                 if (cellw) {
-                    f32x4 sum = acc + scratch[(wave + 4) * 64 + lane] + pre4;
+                    const f32x4 sum = acc + scratch[(wave - 4) * 64 + lane] + pre4 + (l == 2 ? aheadB : aheadA);
                     const int u = 4 * unit + q;
                     const bool valid = row < B, active = valid && t < len;
                     float& hreg = l == 2 ? hB : hA;
@@ -390,21 +409,19 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
                     const bool to_above = l < 2;
                     if (a.drop && to_above && active)
                         hd = hreg * dropout_scale(seed, a.stream_base + (uint64_t)l * T + t, (uint64_t)((int64_t)row * H + u), a.drop_p);
-                    const int xoff = ((l * 2 + (t & 1)) * slot_f) * 4 + ((unit * kRows + row) * 4) * 4;
+                    const int uoff = ((unit * kRows + row) * 4) * 4;
                     {
                         const float hv = valid ? hreg : 0.f;
                         const f32x4 pk = f32x4{hv, __shfl(hv, j + 16, 64), __shfl(hv, j + 32, 64), __shfl(hv, j + 48, 64)};
-                        if (q == 0) stx(rs, xoff, pk);
+                        if (q == 0) stx(rs, hoff(l, t) + uoff, pk);
                     }
                     if (a.drop && to_above) {
                         const f32x4 pk = f32x4{hd, __shfl(hd, j + 16, 64), __shfl(hd, j + 32, 64), __shfl(hd, j + 48, 64)};
-                        if (q == 0) stx(rs, a.xd_off + xoff, pk);
+                        if (q == 0) stx(rs, xdoff(l, t) + uoff, pk);
                     }
                     st_g[0] = active ? gi : 0.f; st_g[1] = active ? gf : 0.f; st_g[2] = active ? gg : 0.f; st_g[3] = active ? go : 0.f;
                     st_hd = hd; st_on = valid;
                 }
-            } else {
-                __syncthreads();
             }
             MMQG_DSTAMP(5 + ph)
             gb::arrive(bar);
@@ -417,6 +434,13 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
                 a.hs[e] = l == 2 ? hB : hA; a.cs[e] = l == 2 ? cB : cA;
                 if (a.drop && l < 2) a.hdrop[(((int64_t)l * T + t) * B + row) * H + u] = st_hd;
             }
+            // idle windows: the recurrent half of the NEXT product of this workgroup's layer, from an h that an earlier
+            // barrier published — layer 1's h_1(t-1) W_hh1^T while layer 0 runs, layer 0's h_0(t) W_hh0^T (for token
+            // t + 1) while layer 1 runs
+            if (ph == 0 && wg_l12 && cellw)
+                aheadA = wave_product<kRingAhead>(rs, make_prod(H / 16, 0, 1, hoff(1, t - 1), wb0 + (H / 16) * 64, lane_off), lds, lane);
+            if (ph == 1 && wg_l0 && cellw && t + 1 < T)
+                aheadA = wave_product<kRingAhead>(rs, make_prod(H / 16, 0, 1, hoff(0, t), wb0 + (Cw / 16) * 64, lane_off), lds, lane);
             ok = gb::wait(bar);
             if (!ok) break;
         }
@@ -431,14 +455,14 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
 inline int64_t align_up(int64_t v, int64_t al) { return (v + al - 1) / al * al; }
 
 struct WsLayout { int64_t bar, hx, xd, cx, sx, sticky, total; };
-WsLayout ws_layout(int H, int Cw, int ldS) {
+WsLayout ws_layout(int T, int H, int Cw, int ldS) {
     WsLayout w;
     w.bar = 0;
     w.hx = align_up((int64_t)sizeof(gb::XBar), 256);
-    w.xd = w.hx + (int64_t)3 * 2 * kRows * H * 4;
-    w.cx = w.xd + (int64_t)2 * 2 * kRows * H * 4;
-    w.sx = w.cx + (int64_t)kRows * Cw * 4;
-    w.sticky = align_up(w.sx + (int64_t)kRows * ldS * 4, 256);
+    w.xd = w.hx + (int64_t)3 * (T + 1) * kRows * H * 4;
+    w.cx = w.xd + (int64_t)2 * T * kRows * H * 4;
+    w.sx = w.cx + (int64_t)T * kRows * Cw * 4;
+    w.sticky = align_up(w.sx + (int64_t)T * kRows * ldS * 4, 256);
     w.total = w.sticky + 256;
     return w;
 }
@@ -460,8 +484,12 @@ static int64_t g_dtrace_words = 0;
 void decoder_persist_set_trace(unsigned long long* buf, int64_t words) { g_dtrace_buf = buf; g_dtrace_words = buf ? words : 0; }
 
 bool decoder_persist_shape_ok(const mmqg_decoder_seq& d) {
-    static const bool on = [] { const char* e = getenv("MMQG_PERSIST_DEC"); return e && atoi(e) != 0; }();
-    if (!on) return false;
+    static const bool off = [] {
+        const char* e = getenv("MMQG_NO_PERSIST");
+        const char* f = getenv("MMQG_NO_PERSIST_DEC");
+        return (e && atoi(e) != 0) || (f && atoi(f) != 0);
+    }();
+    if (off) return false;
     const mmqg_attn_values& v = d.values;
     const int H = d.H, Cw = v.H + v.Da + v.Dv, S = v.Lt + 2 * v.Lav;
     if (d.L != 3 || d.T < 2 || d.B < 1 || d.B > kRows) return false;
@@ -475,7 +503,7 @@ int64_t decoder_persist_ws_bytes(const mmqg_decoder_seq& d) {
     if (!decoder_persist_shape_ok(d)) return 0;
     persist_runtime_prepare();
     const mmqg_attn_values& v = d.values;
-    return ws_layout(d.H, v.H + v.Da + v.Dv, d.ld_attn).total;
+    return ws_layout(d.T, d.H, v.H + v.Da + v.Dv, d.ld_attn).total;
 }
 
 // 0 = done (the whole time loop), 1 = not taken, < 0 = error
@@ -483,7 +511,8 @@ int decoder_seq_fwd_persistent(const mmqg_decoder_seq& d, hipStream_t s) {
     if (!d.persist_ws || !decoder_persist_shape_ok(d)) return 1;
     const mmqg_attn_values& v = d.values;
     const int T = d.T, B = d.B, H = d.H, E = d.E, Cw = v.H + v.Da + v.Dv, S = v.Lt + 2 * v.Lav;
-    const WsLayout wl = ws_layout(H, Cw, d.ld_attn);
+    const WsLayout wl = ws_layout(T, H, Cw, d.ld_attn);
+    if (wl.sticky - wl.hx >= (int64_t)1 << 31) return 1;
     if (d.persist_ws_bytes < wl.total || !aligned16(d.persist_ws)) return 1;
     const int G = std::min(persist_device_cus(), 256);
     if (G < 2 * (H / 4)) return 1;
@@ -521,9 +550,10 @@ int decoder_seq_fwd_persistent(const mmqg_decoder_seq& d, hipStream_t s) {
 
     char* ws = reinterpret_cast<char*>(d.persist_ws);
     const int64_t BH = (int64_t)B * H;
-    // (slot 0 of hs / cs already holds the initial state: decoder_seq_fwd) the barrier block and the exchange buffers
-    // start from zero
-    const CopySeg init{reinterpret_cast<float*>(ws), nullptr, wl.sticky / 4};
+    // (slot 0 of hs / cs already holds the initial state: decoder_seq_fwd) the barrier block starts from zero.  The
+    // exchange buffers need no initial value: every slot is written before it is read, and rows >= B, which nobody writes,
+    // only feed MFMA output rows >= B, which nobody stores.
+    const CopySeg init{reinterpret_cast<float*>(ws), nullptr, wl.hx / 4};
     MMQG_TRY(copy_or_zero_multi(&init, 1, s));
     DecArgs a{};
     a.T = T; a.B = B; a.H = H; a.E = E; a.Cw = Cw; a.S = S; a.ldS = d.ld_attn; a.G = G;

@@ -430,7 +430,7 @@ int decoder_seq_fwd(const mmqg_decoder_seq& d, hipStream_t s) {
                           d.b_ih[0], d.b_hh[0], 0, d.gates, 4 * H, -1, s));
     }
     if (d.phase == 1) return 0;
-    if (d.persist_ws && !g_no_fuse()) {      // the whole time loop as one persistent launch (persist_dec.hip; opt-in)
+    if (d.persist_ws && !g_no_fuse()) {      // the whole time loop as one persistent launch (persist_dec.hip)
         const int rc = decoder_seq_fwd_persistent(d, s);
         if (rc <= 0) return rc;
     }

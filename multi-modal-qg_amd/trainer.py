@@ -351,8 +351,8 @@ class BatchedTrainer:
         if n > 0:
             w["attn_ws"] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)
             dd.attn_ws, dd.attn_ws_bytes = w["attn_ws"].data_ptr(), n
-        # the decoder's whole forward time loop as ONE persistent launch (csrc/persist_dec.hip): opt-in
-        # (MMQG_PERSIST_DEC=1; the library returns 0 bytes otherwise)
+        # the decoder's whole forward time loop as ONE persistent launch (csrc/persist_dec.hip) when the library
+        # takes the shape (0 bytes otherwise, or with MMQG_NO_PERSIST_DEC=1)
         n = int(_lib.load().mmqg_decoder_seq_persist_ws_bytes(C.byref(dd)))
         if n > 0:
             w["dec_pws"] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)

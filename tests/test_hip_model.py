@@ -516,8 +516,9 @@ def test_kernel_families_give_the_same_gradients_at_bench_size(mm, tmp_path):
                              # persistent launch; the opt-in paths (fused score + attention launch, forward look-ahead
                              # products, late weight transposes) must give the same step too
                              ("nopair", {"MMQG_NO_BWD_PAIR": "1"}, ()), ("nopersistbwd", {"MMQG_NO_PERSIST_BWD": "1"}, ()),
-                             ("attnfuse", {"MMQG_ATTN_FUSE": "1"}, ()), ("aheadfwd", {"MMQG_AHEAD_FWD": "1"}, ()),
-                             ("persistdec", {"MMQG_PERSIST_DEC": "1"}, ()), ("persistdec_graph", {"MMQG_PERSIST_DEC": "1"}, ("--graph",)),
+                             ("attnfuse", {"MMQG_ATTN_FUSE": "1", "MMQG_NO_PERSIST_DEC": "1"}, ()),
+                             ("aheadfwd", {"MMQG_AHEAD_FWD": "1", "MMQG_NO_PERSIST_DEC": "1"}, ()),
+                             ("nopersistdec", {"MMQG_NO_PERSIST_DEC": "1"}, ()),
                              ("latetr", {"MMQG_TRANSPOSES_LATE": "1"}, ("--graph",))]),
             ("config5", 128, [("x3off", {"MMQG_GEMM_X3": "0"}, ()), ("nowide", {"MMQG_NO_WIDE": "1"}, ()),
                               ("nowidebwd", {"MMQG_NO_WIDE_BWD": "1"}, ()), ("wideksl1", {"MMQG_WIDE_MAX_KSL": "1"}, ())])):
@@ -531,8 +532,8 @@ def test_kernel_families_give_the_same_gradients_at_bench_size(mm, tmp_path):
                 assert int(got["projection_kernel"]) != 2
             if tag in ("nopersist", "nofuse"):
                 assert int(got["persist_launches"]) == 0
-            assert (int(got["decoder_persist_launches"]) > 0) == tag.startswith("persistdec"), \
-                "the decoder's persistent forward loop is opt-in and must run when asked for"
+            assert (int(got["decoder_persist_launches"]) > 0) == (workload == "config2" and tag not in ("nopersist", "nofuse", "nopersistdec", "attnfuse", "aheadfwd")), \
+                "the decoder's persistent forward loop must run at config 2 unless switched off"
             if tag in ("nopersist", "nofuse", "nopersistbwd"):
                 assert int(got["persist_bwd_launches"]) == 0
             elif workload == "config2":

@@ -1,12 +1,11 @@
 #!/usr/bin/env python3
-"""Where a token of the persistent decoder FORWARD loop (csrc/persist_dec.hip, MMQG_PERSIST_DEC=1) spends its time:
+"""Where a token of the persistent decoder FORWARD loop (csrc/persist_dec.hip) spends its time:
 per-(workgroup, token) wall-clock stamps (100 MHz) written by the stamped instantiation of the kernel.
-    MMQG_PERSIST_DEC=1 python tools/persist_dec_trace.py [workload]"""
+    python tools/persist_dec_trace.py [workload]"""
 import ctypes as C
 import os
 import sys
 
-os.environ.setdefault("MMQG_PERSIST_DEC", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mmqg_amd  # noqa
