@@ -143,8 +143,13 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
     const int g = blockIdx.x;
     const bool wg_l0 = g < NU, wg_l12 = g >= NU && g < 2 * NU;
     const int unit = wg_l0 ? g : g - NU;
+    // score tiles (16 score columns x K = H): s_split workgroups per tile, each with 4 / s_split blocks of 16 questions
+    // (rbw per workgroup) and its waves k-split 8 / rbw ways — as many of the layer-0 workgroups as fit take part
     const int n_stile = (a.S + 15) / 16;
-    const bool wg_s = g < n_stile;
+    const int s_split = 4 * n_stile <= NU ? 4 : (2 * n_stile <= NU ? 2 : 1);
+    const bool wg_s = g < n_stile * s_split;
+    const int s_tile = g / s_split, s_rbw = 4 / s_split, s_kparts = kWaves / s_rbw;
+    const int s_rb = (g % s_split) * s_rbw + wave % s_rbw, s_kp = wave / s_rbw;
     const int slot_f = kRows * H;                  // floats per (layer, token) slot of hx / xd
     // Every (layer, token) has its OWN slot in the exchange buffers: a line is written once (write-through) and only read
     // after the barrier behind its production, so no cache on the chip can hold an older copy of it — the loads are
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
     if (wg_s) {
         for (int idx = tid; idx < nchs * 64; idx += kThreads) {
             const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
-            const int srow = min(16 * g + i, a.S - 1);
+            const int srow = min(16 * s_tile + i, a.S - 1);
             lds[wbs + idx] = *reinterpret_cast<const f32x4*>(a.w_attn_h + (int64_t)srow * a.ld_wa + 16 * c + 4 * kq);
         }
     }
@@ -231,13 +236,21 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hB : 0.f), rs, hoff(2, -1) + ((unit * kRows + row) * 4 + q) * 4, 0, 16);
     }
 
-    // ---- attention-phase roles: waves 0-3 = two text items (two waves each: rows halved), waves 4-5 = two video items,
-    // wave 6 = one audio item (32 columns); item lists are question-major so that the batch's items spread over the CUs
+    // ---- attention-phase roles: waves 1-4 = two text items (two waves each: rows halved), waves 5-6 = two video items,
+    // wave 7 = one audio item (32 columns); wave 0, whose lane 0 polls the barriers, has none (its first poll would wait
+    // for the value rows it had in flight).  Item lists are question-major so that the batch's items spread over the CUs;
+    // the host only takes shapes whose items fit one round (2 text + 2 video + 1 audio item per workgroup).
     const int chunks_t = (a.v.H + 63) / 64, chunks_v = (a.v.Dv + 63) / 64, chunks_a = (a.v.Da + 31) / 32;
-    const int n_text = B * chunks_t, n_video = B * chunks_v, n_audio = B * chunks_a;
-    const int text_rounds = (n_text + 2 * a.G - 1) / (2 * a.G), video_rounds = (n_video + 2 * a.G - 1) / (2 * a.G),
-              audio_rounds = (n_audio + a.G - 1) / a.G;
-    const int att_rounds = max(text_rounds, max(video_rounds, audio_rounds));
+    int it_mod = -1, it_half = 0, it_nhalf = 1, it_b = 0, it_chunk = 0;
+    {
+        int item = 0;
+        if (wave >= 1 && wave <= 4) { item = 2 * g + ((wave - 1) >> 1); it_half = (wave - 1) & 1; it_nhalf = 2; if (item < B * chunks_t) it_mod = 0; }
+        else if (wave == 5 || wave == 6) { item = 2 * g + (wave - 5); if (item < B * chunks_v) it_mod = 2; }
+        else if (wave == 7) { item = g; if (item < B * chunks_a) it_mod = 1; }
+        const int nchunks = it_mod == 0 ? chunks_t : (it_mod == 2 ? chunks_v : chunks_a);
+        it_b = item / nchunks; it_chunk = item - it_b * nchunks;
+    }
+    const int comb_slot = (wave - 1) >> 1;          // text items: where the second wave leaves its partial context
 
     gb::Ctx bar;
     bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
@@ -252,71 +265,70 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
         MMQG_DSTAMP(0)
         // =========================================================== S: scores(t) into sx
         if (wg_s) {
-            const int b = mb * 16 + j, col = 16 * g + 4 * q;
-            const bool st = cellw && b < B && col < a.ldS;
+            const int b = s_rb * 16 + j, col = 16 * s_tile + 4 * q;
+            const bool st = s_kp == 0 && b < B && col < a.ldS;
             f32x4 pre = f32x4{0.f, 0.f, 0.f, 0.f};
             if (st) pre = *reinterpret_cast<const f32x4*>(a.pre_scores + ((int64_t)t * B + b) * a.ldS + col);
-            const WaveProd w = make_prod(nchs, ks, 2, hoff(2, t - 1), wbs, lane_off);      // h_top(t-1)
-            const f32x4 acc = wave_product<kRingLate>(rs, w, lds, lane);
-            if (!cellw) scratch[wave * 64 + lane] = acc;
+            const WaveProd w = make_prod(nchs, s_kp, s_kparts, hoff(2, t - 1), wbs, (q * kRows + b) * 16);      // h_top(t-1)
+            f32x4 acc = s_kparts >= 4 ? wave_product<8>(rs, w, lds, lane) : wave_product<kRingLate>(rs, w, lds, lane);
+            if (s_kp != 0) scratch[wave * 64 + lane] = acc;
             __syncthreads();
-            if (st) stx(rs, sxoff(t) + (b * a.ldS + col) * 4, acc + scratch[(wave - 4) * 64 + lane] + pre);
+            if (st) {
+                for (int kp = 1; kp < s_kparts; ++kp) acc += scratch[(kp * s_rbw + wave) * 64 + lane];
+                stx(rs, sxoff(t) + (b * a.ldS + col) * 4, acc + pre);
+            }
         }
         MMQG_DSTAMP(1)
         gb::arrive(bar);
         // idle window of the layer-1/2 workgroups: the recurrent half of layer 2's product, h_2(t-1) W_hh2^T
         if (wg_l12 && cellw) aheadB = wave_product<kRingAhead>(rs, make_prod(H / 16, 0, 1, hoff(2, t - 1), wb1 + (H / 16) * 64, lane_off), lds, lane);
+        // ... and of every wave with an attention item: the first 16 KB of its value rows are on their way while the score
+        // tiles finish and the barrier turns (they do not depend on the scores)
+        constexpr int kU = 8;
+        f32x4 cur[kU], nxt[kU];
+        int L = 0, D = 0, seg_off = 0, ctx_off = 0, valid = 0, r_lo = 0, r_hi = 0, col = 0, lanes = 16, groups = 4, rgp = 0, last = 0, coff = 0, rowb = 0;
+        bool col_ok = false, stream = false;
+        const float* base = a.v.text;
+        if (it_mod >= 0) {
+            const int b = it_b;
+            const int cwidth = it_mod == 1 ? 32 : 64;
+            if (it_mod == 0) { base = a.v.text + (int64_t)b * a.v.text_stride_b; L = a.v.Lt; D = a.v.H; seg_off = 0; ctx_off = 0; valid = a.v.text_len ? a.v.text_len[b] : L; }
+            else if (it_mod == 1) { base = a.v.audio + (int64_t)b * a.v.audio_stride_b; L = a.v.Lav; D = a.v.Da; seg_off = a.v.Lt; ctx_off = a.v.H; valid = a.v.av_len ? a.v.av_len[b] : L; }
+            else { base = a.v.video + (int64_t)b * a.v.video_stride_b; L = a.v.Lav; D = a.v.Dv; seg_off = a.v.Lt + a.v.Lav; ctx_off = a.v.H + a.v.Da; valid = a.v.av_len ? a.v.av_len[b] : L; }
+            const int n_stream = a.v.zero_past_len ? max(1, min(L, valid)) : L;
+            const int rows_half = (n_stream + it_nhalf - 1) / it_nhalf;       // rows of this wave: all, or its half
+            r_lo = it_half * rows_half; r_hi = min(n_stream, r_lo + rows_half);
+            lanes = cwidth / 4;                                               // float4 column lanes (16, or 8 for audio)
+            groups = 64 / lanes;                                              // row groups (4, or 8)
+            rgp = lane / lanes;
+            col = it_chunk * cwidth + 4 * (lane % lanes);
+            col_ok = col < D;
+            last = max(r_hi - 1, r_lo);
+            stream = col_ok && r_hi > r_lo;
+            coff = col * 4; rowb = D * 4;
+        }
+        // (the question's value rows through a buffer descriptor: one 32-bit offset per load instead of a 64-bit address)
+        const auto rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, L * D * 4, 0x00020000);
+        auto fetch = [&rv, coff, rowb, last, groups](f32x4 (&dst)[kU], int first) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, coff + min(first + u * groups, last) * rowb, 0, 0));
+        };
+        if (stream) { fetch(cur, r_lo + rgp); fetch(nxt, r_lo + rgp + kU * groups); }
         ok = gb::wait(bar);
         if (!ok) break;
         MMQG_DSTAMP(2)
         // =========================================================== ATT: softmax + contexts of step t
-        for (int rnd = 0; rnd < att_rounds; ++rnd) {
-            // this wave's item of the round
-            int modality = -1, item = 0, half = 0, nhalf = 1;
-            if (wave < 4) { item = (rnd * a.G + g) * 2 + (wave >> 1); half = wave & 1; nhalf = 2; if (item < n_text) modality = 0; }
-            else if (wave < 6) { item = (rnd * a.G + g) * 2 + (wave - 4); if (item < n_video) modality = 2; }
-            else if (wave == 6) { item = rnd * a.G + g; if (item < n_audio) modality = 1; }
+        {
             f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
             float inv = 0.f;
-            int b = 0, chunk = 0, D = 0, L = 0, seg_off = 0, ctx_off = 0, col = 0;
-            bool col_ok = false;
-            float* e = att_e + min(wave, 6) * kMaxSeg;
-            if (modality >= 0) {
-                const int nchunks = modality == 0 ? chunks_t : (modality == 2 ? chunks_v : chunks_a);
-                const int cwidth = modality == 1 ? 32 : 64;
-                b = item / nchunks; chunk = item - b * nchunks;
-                const float* base; int valid;
-                if (modality == 0) { base = a.v.text + (int64_t)b * a.v.text_stride_b; L = a.v.Lt; D = a.v.H; seg_off = 0; ctx_off = 0; valid = a.v.text_len ? a.v.text_len[b] : L; }
-                else if (modality == 1) { base = a.v.audio + (int64_t)b * a.v.audio_stride_b; L = a.v.Lav; D = a.v.Da; seg_off = a.v.Lt; ctx_off = a.v.H; valid = a.v.av_len ? a.v.av_len[b] : L; }
-                else { base = a.v.video + (int64_t)b * a.v.video_stride_b; L = a.v.Lav; D = a.v.Dv; seg_off = a.v.Lt + a.v.Lav; ctx_off = a.v.H + a.v.Da; valid = a.v.av_len ? a.v.av_len[b] : L; }
+            float* e = att_e + max(wave - 1, 0) * kMaxSeg;
+            if (it_mod >= 0) {
                 const bool masked = a.v.mask_mode == MMQG_MASK_INTENDED;
-                const int n_stream = a.v.zero_past_len ? max(1, min(L, valid)) : L;
-                // rows of this wave: all, or its half
-                const int rows_half = (n_stream + nhalf - 1) / nhalf;
-                const int r_lo = half * rows_half, r_hi = min(n_stream, r_lo + rows_half);
-                const int lanes = cwidth / 4;                          // float4 column lanes (16, or 8 for audio)
-                const int groups = 64 / lanes;                         // row groups (4, or 8)
-                const int cl = lane % lanes, rgp = lane / lanes;
-                col = chunk * cwidth + 4 * cl;
-                col_ok = col < D;
-                // the question's value rows through a buffer descriptor: one 32-bit offset per load instead of a 64-bit address
-                const auto rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, L * D * 4, 0x00020000);
-                const int coff = col * 4, rowb = D * 4;
-                // first loads of the value stream go out before the softmax
-                constexpr int kU = 8;
-                f32x4 cur[kU], nxt[kU];
-                const int last = max(r_hi - 1, r_lo);
-                auto fetch = [&rv, coff, rowb, last, groups](f32x4 (&dst)[kU], int first) {
-#pragma unroll
-                    for (int u = 0; u < kU; ++u)
-                        dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, coff + min(first + u * groups, last) * rowb, 0, 0));
-                };
-                const bool stream = col_ok && r_hi > r_lo;
-                if (stream) { fetch(cur, r_lo + rgp); fetch(nxt, r_lo + rgp + kU * groups); }
                 // softmax of the whole segment (both halves of a split item do it)
                 float lmax = -INFINITY;
                 for (int i = lane; i < L; i += 64) {
-                    float s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, sxoff(t) + (b * a.ldS + seg_off + i) * 4, 0, 0));
+                    float s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, sxoff(t) + (it_b * a.ldS + seg_off + i) * 4, 0, 0));
                     if (masked && i >= valid) s = -INFINITY;
                     e[i] = s;
                     lmax = fmaxf(lmax, s);
@@ -331,8 +343,8 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
                 lsum = wave_sum(lsum);
                 inv = 1.0f / lsum;
                 __builtin_amdgcn_wave_barrier();
-                if (chunk == 0 && half == 0) {
-                    float* arow = a.attn + ((int64_t)t * B + b) * a.ldS + seg_off;
+                if (it_chunk == 0 && it_half == 0) {
+                    float* arow = a.attn + ((int64_t)t * B + it_b) * a.ldS + seg_off;
                     for (int i = lane; i < L; i += 64) arow[i] = e[i] * inv;
                 }
                 f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -349,25 +361,21 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
                     }
                 }
                 acc0 += acc1;
-                // combine the row groups of the wave (lanes with equal cl)
+                // combine the row groups of the wave (lanes with equal column lane)
                 for (int off = lanes; off < 64; off <<= 1) {
                     acc0.x += __shfl_xor(acc0.x, off, 64); acc0.y += __shfl_xor(acc0.y, off, 64);
                     acc0.z += __shfl_xor(acc0.z, off, 64); acc0.w += __shfl_xor(acc0.w, off, 64);
                 }
                 part = acc0;
-                if (nhalf == 2 && half == 1 && lane < 16) att_comb[(wave >> 1) * 16 + lane] = part;
+                if (it_nhalf == 2 && it_half == 1 && lane < 16) att_comb[comb_slot * 16 + lane] = part;
             }
             __syncthreads();                       // (every wave, with or without an item)
-            if (modality >= 0 && half == 0) {
-                const int lanes = modality == 1 ? 8 : 16;
-                if (lane < lanes && col_ok) {
-                    if (nhalf == 2) part += att_comb[(wave >> 1) * 16 + lane];
-                    part = part * inv;
-                    *reinterpret_cast<f32x4*>(a.ctx + ((int64_t)t * B + b) * Cw + ctx_off + col) = part;      // saved for backward
-                    stx(rs, cxoff(t) + (((ctx_off + col) >> 2) * kRows + b) * 16, part);                        // operand of layer 0
-                }
+            if (it_mod >= 0 && it_half == 0 && lane < lanes && col_ok) {
+                if (it_nhalf == 2) part += att_comb[comb_slot * 16 + lane];
+                part = part * inv;
+                *reinterpret_cast<f32x4*>(a.ctx + ((int64_t)t * B + it_b) * Cw + ctx_off + col) = part;      // saved for backward
+                stx(rs, cxoff(t) + (((ctx_off + col) >> 2) * kRows + it_b) * 16, part);                        // operand of layer 0
             }
-            __syncthreads();
         }
         MMQG_DSTAMP(3)
         ok = gb::sync(bar);
@@ -493,9 +501,13 @@ bool decoder_persist_shape_ok(const mmqg_decoder_seq& d) {
     const mmqg_attn_values& v = d.values;
     const int H = d.H, Cw = v.H + v.Da + v.Dv, S = v.Lt + 2 * v.Lav;
     if (d.L != 3 || d.T < 2 || d.B < 1 || d.B > kRows) return false;
-    if (H % 16 || Cw % 16 || v.H != H || v.H % 4 || v.Da % 4 || v.Dv % 4 || d.E % 4 || d.ld_attn % 4) return false;
+    if (H < 128 || H % 16 || Cw % 16 || v.H != H || v.H % 4 || v.Da % 4 || v.Dv % 4 || d.E % 4 || d.ld_attn % 4) return false;
     if (v.Lt > kMaxSeg || v.Lav > kMaxSeg) return false;
-    if ((S + 15) / 16 > H / 4) return false;
+    if ((S + 15) / 16 > H / 4) return false;          // the score tiles live on the layer-0 workgroups
+    {   // the attention items of a token must fit one round: 2 text + 2 video + 1 audio item per workgroup
+        const int G = std::min(persist_device_cus(), 256);
+        if (d.B * ((v.H + 63) / 64) > 2 * G || d.B * ((v.Dv + 63) / 64) > 2 * G || d.B * ((v.Da + 31) / 32) > G) return false;
+    }
     return lds_need(H, Cw) <= kLdsBudget;
 }
 
