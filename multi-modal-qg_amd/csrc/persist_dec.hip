@@ -280,9 +280,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
         }
         MMQG_DSTAMP(1)
         gb::arrive(bar);
-        // idle window of the layer-1/2 workgroups: the recurrent half of layer 2's product, h_2(t-1) W_hh2^T
-        if (wg_l12 && cellw) aheadB = wave_product<kRingAhead>(rs, make_prod(H / 16, 0, 1, hoff(2, t - 1), wb1 + (H / 16) * 64, lane_off), lds, lane);
-        // ... and of every wave with an attention item: the first 16 KB of its value rows are on their way while the score
+        // idle window of every wave with an attention item: the first 16 KB of its value rows are on their way while the score
         // tiles finish and the barrier turns (they do not depend on the scores)
         constexpr int kU = 8;
         f32x4 cur[kU], nxt[kU];
@@ -378,7 +376,11 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
             }
         }
         MMQG_DSTAMP(3)
-        ok = gb::sync(bar);
+        gb::arrive(bar);
+        // idle window of the layer-1/2 workgroups (they have nothing to do until layer 0 is through): the recurrent half of
+        // layer 2's product, h_2(t-1) W_hh2^T
+        if (wg_l12 && cellw) aheadB = wave_product<kRingAhead>(rs, make_prod(H / 16, 0, 1, hoff(2, t - 1), wb1 + (H / 16) * 64, lane_off), lds, lane);
+        ok = gb::wait(bar);
         if (!ok) break;
         MMQG_DSTAMP(4)
         // =========================================================== L0 / L1 / L2
