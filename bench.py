@@ -20,6 +20,13 @@ Besides throughput the line carries
                 batch is re-read every decode step and stays in the 256 MiB Infinity Cache), and
                 ``achieved_beyond_mall`` = the same launches rotated over enough distinct value
                 tensors (> 2 x 256 MiB) that every row comes from HBM;
+                Where the decoder's forward time loop runs as ONE persistent launch (csrc/persist_dec.hip: B <= 64,
+                three layers, weights within the chip's LDS) no attention launch exists in the step any more: the
+                attention is a phase of that kernel, and ``roofline`` is then that phase — the same algorithmic bytes
+                per token over the window from the first value-row load to the last context stored, read from the
+                device wall-clock stamps of the kernel's stamped instantiation — with the whole launch's duration
+                (HIP events; rocprofv3's average for decoder_persist_fwd_kernel agrees) beside it and the standalone
+                kernel's figures under ``standalone_kernel``;
   roofline_mfma the vocabulary-projection GEMM (fp32 MFMA), same method;
   cpu_baseline  the CPU oracle (``oracle/``: the reference's batch-1 loop restated, kind "port")
                 timed on this box's host cores on a bounded sample of the same workload.
@@ -155,10 +162,10 @@ def source_sha(rel):
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def recorded_traffic(workload_key):
-    """PMC-measured HBM-side bytes per attention launch (profiles/attn_traffic.json, written by
-    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes).  Only a record
-    taken on the kernel source that is loaded now counts; anything else reports null."""
+def recorded_traffic(workload_key, source="attention.hip"):
+    """PMC-measured HBM-side bytes per launch (profiles/attn_traffic.json, written by tools/pmc_traffic.py from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes).  Only a record taken on the kernel source that is
+    loaded now counts; anything else reports null."""
     tpath = os.path.join(ROOT, "profiles", "attn_traffic.json")
     try:
         rec = json.load(open(tpath)).get(workload_key)
@@ -166,22 +173,57 @@ def recorded_traffic(workload_key):
         return None, "no profiles/attn_traffic.json"
     if not rec:
         return None, f"no PMC record for {workload_key}"
-    if rec.get("source_sha") != source_sha("multi-modal-qg_amd/csrc/attention.hip"):
-        return None, "PMC record was taken on a different attention.hip"
+    if rec.get("source_sha") != source_sha("multi-modal-qg_amd/csrc/" + source):
+        return None, "PMC record was taken on a different " + source
     return rec.get("hbm_bytes_per_launch"), f"{rec.get('kernel')} grid {rec.get('grid')}"
 
 
-def recorded_in_step(workload_key):
-    """In-step duration of the attention forward launch (profiles/attn_in_step.json, written by tools/attn_in_step.py
-    from a rocprofv3 kernel-trace of `bench.py --kernel-iters 0`): only a record taken on the attention.hip that is
-    loaded now counts."""
+def recorded_in_step(workload_key, source="attention.hip"):
+    """In-step duration of the attention forward launch — or, where the decoder's forward loop is one persistent
+    launch, of that launch — (profiles/attn_in_step.json, written by tools/attn_in_step.py from a rocprofv3
+    kernel-trace of `bench.py --kernel-iters 0`): only a record taken on the kernel source that is loaded now counts."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "attn_in_step.json"))).get(workload_key)
     except Exception:
         return None
-    if not rec or rec.get("source_sha") != source_sha("multi-modal-qg_amd/csrc/attention.hip"):
+    if not rec or rec.get("source_sha") != source_sha("multi-modal-qg_amd/csrc/" + source):
         return None
     return rec
+
+
+def decoder_persist_probe(tr, reps=3):
+    """The decoder's persistent forward launch under its stamped instantiation (mmqg_decoder_persist_set_trace): per
+    (workgroup, token) device wall-clock stamps at 100 MHz.  Returns None when the step does not run that kernel."""
+    from mmqg_amd import _lib, ops
+    lib = _lib.load()
+    if not tr.d_dec.persist_ws:
+        return None
+    G, T = 256, tr.Td
+    buf = torch.zeros(G * T * 8, device=tr.dev, dtype=torch.int64)
+    n0 = lib.mmqg_decoder_persist_launch_count()
+    tr.d_dec.phase = 2
+    try:
+        for _ in range(reps):
+            _lib.check(lib.mmqg_decoder_persist_set_trace(buf.data_ptr(), buf.numel()))
+            _lib.check(lib.mmqg_decoder_seq_fwd(C.byref(tr.d_dec), ops._stream()))
+            _lib.check(lib.mmqg_decoder_persist_set_trace(None, 0))
+            torch.cuda.synchronize()
+    finally:
+        tr.d_dec.phase = 0
+    if lib.mmqg_decoder_persist_launch_count() != n0 + reps:
+        return None
+    t = buf.view(G, T, 8).cpu().double() * 0.01            # us
+    t = t[t[:, 0, 0] > 0]                                  # workgroups that ran (min(CUs, 256))
+    mid = slice(2, T - 2) if T > 6 else slice(0, T)
+    start = t[:, :, 0].min(0).values
+    period = float((start[1:] - start[:-1])[mid].mean()) if T > 1 else float("nan")
+    # attention window of a token: from the first workgroup that has arrived at the score barrier (its waves then issue
+    # the first loads of their value rows) to the last workgroup's contexts stored
+    win = (t[:, :, 3].max(0).values - t[:, :, 1].min(0).values)[mid]
+    after = (t[:, :, 3].max(0).values - t[:, :, 2].min(0).values)[mid]
+    return {"workgroups": int(t.shape[0]), "tokens": T, "us_per_token": round(period, 2),
+            "attention_window_us": round(float(win.mean()), 2), "attention_after_scores_us": round(float(after.mean()), 2),
+            "loop_us": round(float(t[:, -1, 7].max() - t[:, 0, 0].min()), 1)}
 
 
 def graph_time(fn, reps=10):
@@ -241,7 +283,9 @@ def loop_rooflines(tr, w):
     text_flop = 2.0 * B * (4 * H * H + (L - 1) * 4 * H * 2 * H)           # per diagonal, all layers (input product hoisted)
     out = {}
     for name, fn, units, unit, flop, nbytes, stages in (
-            ("decoder_fwd", dec_fwd, Td, "token", dec_flop, dec_bytes, "5 dependent launches per token"),
+            ("decoder_fwd", dec_fwd, Td, "token", dec_flop, dec_bytes,
+             "persistent: 5 device-wide barriers per token, recurrent weights resident in LDS" if tr.d_dec.persist_ws
+             else "5 dependent launches per token"),
             ("decoder_bwd", dec_bwd, Td, "token", 2 * dec_flop, dec_bytes + B * vals, "5 dependent launches per token"),
             ("text_encoder_fwd", text_fwd, Tc + L - 1, "diagonal", text_flop, 4 * B * 2 * H * L,
              "persistent: 1 device-wide barrier per diagonal, weights resident in LDS"),
@@ -323,6 +367,42 @@ def kernel_rooflines(tr, w, iters):
             "frac_beyond_mall": round(nbytes / dtc / 1e9 / HBM_PEAK_GBS, 4),
             "us_per_launch_beyond_mall": round(dtc * 1e6, 2),
             "beyond_mall_working_set_bytes": int(n_rot * vbytes)}
+    probe = decoder_persist_probe(tr)
+    if probe:
+        # the step runs no attention launch: the forward attention is a phase of the persistent decoder kernel
+        def dec_loop():      # (the stream is looked up inside: a graph capture runs on its own stream)
+            d.phase = 2
+            _lib.check(lib.mmqg_decoder_seq_fwd(C.byref(d), ops._stream()))
+            d.phase = 0
+        dtk = graph_time(dec_loop)
+        win = probe["attention_window_us"] * 1e-6
+        ktraffic, knote = recorded_traffic(key + ":decoder_persist_fwd", "persist_dec.hip")
+        krec = recorded_in_step(key, "persist_dec.hip")
+        lstm_w = 4 * (4 * tr.H * (Cw + tr.H) + (tr.L - 1) * 4 * tr.H * 2 * tr.H) + 4 * tr.S * tr.H
+        kbytes = Td * nbytes + lstm_w + 4 * Td * B * (3 * 4 * tr.H + 3 * 2 * tr.H)      # + weights once + saved gates, h, c
+        standalone = roof
+        roof = {"kernel": "decoder_persist_fwd_kernel: attention phase (three softmaxes + three contexts of one token, %d "
+                          "questions)" % B, "bound": "hbm", "achieved": round(nbytes / win / 1e9, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(nbytes / win / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_basis": "algorithmic bytes of one token's attention / the phase's window inside the persistent launch "
+                              "(first workgroup past its score tile, whose waves then issue the first value-row loads, to the "
+                              "last workgroup's contexts stored), device wall-clock stamps of the stamped instantiation, "
+                              "%d workgroups, mean over the steady-state tokens" % probe["workgroups"],
+                "bytes_per_launch": nbytes, "us_per_launch": probe["attention_window_us"],
+                "unit_of_launch": "one token's attention phase (the kernel launch holds %d of them)" % Td,
+                "window_after_scores_us": probe["attention_after_scores_us"],
+                "traffic": None if ktraffic is None else int(ktraffic / Td),
+                "traffic_source": knote + ("; per launch / %d tokens (includes the 31 MB of recurrent weights read once and "
+                                           "the saved activations)" % Td if ktraffic is not None else ""),
+                "whole_launch": {"kernel": "decoder_persist_fwd_kernel", "us_per_launch": round(dtk * 1e6, 1),
+                                 "basis": "HIP events over replays of the launch (with its 4 KB barrier-block fill) as a graph",
+                                 "us_per_launch_in_step_rocprof": krec["us_per_launch"] if krec else None,
+                                 "tokens_per_launch": Td, "us_per_token_stamps": probe["us_per_token"],
+                                 "algorithmic_bytes_per_launch": int(kbytes),
+                                 "achieved": round(kbytes / dtk / 1e9, 1),
+                                 "frac": round(kbytes / dtk / 1e9 / HBM_PEAK_GBS, 4),
+                                 "bound": "latency: 5 device-wide barriers per token; only the attention phase streams HBM"},
+                "standalone_kernel": standalone}
     # vocabulary projection: logits[Td*B, V] = h_top * W_out^T + b
     R, H, V = Td * B, tr.H, tr.V
     htop = ws["hs_d"][tr.L - 1, 1:].reshape(R, H)

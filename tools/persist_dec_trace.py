@@ -48,3 +48,9 @@ for i, name in enumerate(names):
     print(f"{name:44s} mean {float(d.mean()):6.2f}   slowest workgroup per token {float(d.max(0).values.mean()):6.2f}   fastest {float(d.min(0).values.mean()):6.2f}")
 d = t[:, 3:-2, 0] - t[:, 2:-3, 7]
 print(f"{'wait for L2 barrier (arrive -> next token)':44s} mean {float(d.mean()):6.2f}")
+win = (t[:, 2:-2, 3].max(0).values - t[:, 2:-2, 1].min(0).values)
+after = (t[:, 2:-2, 3].max(0).values - t[:, 2:-2, 2].min(0).values)
+vals = 4 * tr.B * (tr.Lt * tr.H + tr.Lav * tr.Da + tr.Lav * tr.Dv + 2 * tr.S + tr.Cw)
+print(f"attention window (first workgroup past its score tile -> last contexts stored): mean {float(win.mean()):.2f} us = "
+      f"{vals / float(win.mean()) / 1e3:.0f} GB/s for the {vals / 1e6:.1f} MB of a token's attention ({vals / float(win.mean()) / 8e6:.3f} of 8 TB/s); "
+      f"after the score barrier alone: {float(after.mean()):.2f} us")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 --pmc counter CSVs into per-launch HBM-side traffic for one kernel.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <workload> [out.json]
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <workload> [out.json] [source.hip] [key]
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts 128-byte requests as
 64 bytes for wide coalesced streaming reads (MI355X_MICROARCH.md, section HBM), so the read side
@@ -40,8 +40,9 @@ def main():
     out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(ROOT, "profiles", "attn_traffic.json")
     fetch_kib, n1, names, grids = per_launch(fd, "FETCH_SIZE", kernel)
     write_kib, n2, _, _ = per_launch(wd, "WRITE_SIZE", kernel)
-    src = os.path.join(ROOT, "multi-modal-qg_amd", "csrc", "attention.hip")
-    rec = {"kernel": ", ".join(names), "grid": grids, "workgroups": [g // 256 for g in grids],
+    src = os.path.join(ROOT, "multi-modal-qg_amd", "csrc", sys.argv[6] if len(sys.argv) > 6 else "attention.hip")
+    key = sys.argv[7] if len(sys.argv) > 7 else workload
+    rec = {"kernel": ", ".join(names), "grid": grids, "workgroups": [g // (512 if "persist" in kernel else 256) for g in grids],
            "source_sha": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
            "launches_fetch": n1, "launches_write": n2,
            "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,
@@ -49,7 +50,7 @@ def main():
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B), WRITE_SIZE x1; L2 memory-side "
                          "counters, Infinity-Cache hits included"}
     data = json.load(open(out)) if os.path.exists(out) else {}
-    data[workload] = rec
+    data[key] = rec
     json.dump(data, open(out, "w"), indent=1)
     print(json.dumps(rec))
 

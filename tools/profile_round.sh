@@ -22,9 +22,11 @@ for W in $WL; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$W -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --kernel-iters 20 > $OUT/pmc_fetch_$W.log 2>&1 || exit 1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$W -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --kernel-iters 20 > $OUT/pmc_write_$W.log 2>&1 || exit 1
   python3 tools/pmc_traffic.py $OUT/pmc_fetch_$W $OUT/pmc_write_$W attn_softmax_context_fwd_kernel $W profiles/attn_traffic.json || exit 1
+  # (where the decoder's forward loop is one persistent launch: that launch's traffic too; absent at config 5)
+  python3 tools/pmc_traffic.py $OUT/pmc_fetch_$W $OUT/pmc_write_$W decoder_persist_fwd_kernel $W profiles/attn_traffic.json persist_dec.hip $W:decoder_persist_fwd || true
   for k in fetch write; do
     f=$(find $OUT/pmc_${k}_$W -name '*counter_collection.csv' | head -1)
-    (head -1 "$f"; grep attn_softmax_context_fwd "$f" | head -60) > $OUT/pmc_${k}_attn_$W.csv
+    (head -1 "$f"; grep attn_softmax_context_fwd "$f" | head -60; grep decoder_persist_fwd "$f" | head -10) > $OUT/pmc_${k}_attn_$W.csv
   done
   rm -rf $OUT/pmc_fetch_$W $OUT/pmc_write_$W
   echo "== $W: bench line and the kernel stats of the same command"
@@ -33,6 +35,7 @@ for W in $WL; do
   f=$(find $OUT/stats_$W -name '*kernel_stats.csv' | head -1); cp "$f" $OUT/kernel_stats_$W.csv
   rm -rf $OUT/stats_$W
   python3 tools/phase_times.py $W > $OUT/phase_times_$W.txt 2>/dev/null
+  python3 tools/persist_dec_trace.py $W > $OUT/persist_dec_trace_$W.txt 2>/dev/null || rm -f $OUT/persist_dec_trace_$W.txt
 done
 cp profiles/attn_in_step.json profiles/attn_traffic.json $OUT/
 echo profile set done
