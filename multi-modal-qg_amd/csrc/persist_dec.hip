@@ -238,14 +238,15 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
 
     // ---- attention-phase roles: waves 1-4 = two text items (two waves each: rows halved), waves 5-6 = two video items,
     // wave 7 = one audio item (32 columns); wave 0, whose lane 0 polls the barriers, has none (its first poll would wait
-    // for the value rows it had in flight).  Item lists are question-major so that the batch's items spread over the CUs;
+    // for the value rows it had in flight).  Item lists are question-major and a workgroup's two items of a kind lie G apart, so that the items of any batch
+    // spread evenly over the CUs;
     // the host only takes shapes whose items fit one round (2 text + 2 video + 1 audio item per workgroup).
     const int chunks_t = (a.v.H + 63) / 64, chunks_v = (a.v.Dv + 63) / 64, chunks_a = (a.v.Da + 31) / 32;
     int it_mod = -1, it_half = 0, it_nhalf = 1, it_b = 0, it_chunk = 0;
     {
         int item = 0;
-        if (wave >= 1 && wave <= 4) { item = 2 * g + ((wave - 1) >> 1); it_half = (wave - 1) & 1; it_nhalf = 2; if (item < B * chunks_t) it_mod = 0; }
-        else if (wave == 5 || wave == 6) { item = 2 * g + (wave - 5); if (item < B * chunks_v) it_mod = 2; }
+        if (wave >= 1 && wave <= 4) { item = g + ((wave - 1) >> 1) * a.G; it_half = (wave - 1) & 1; it_nhalf = 2; if (item < B * chunks_t) it_mod = 0; }
+        else if (wave == 5 || wave == 6) { item = g + (wave - 5) * a.G; if (item < B * chunks_v) it_mod = 2; }
         else if (wave == 7) { item = g; if (item < B * chunks_a) it_mod = 1; }
         const int nchunks = it_mod == 0 ? chunks_t : (it_mod == 2 ? chunks_v : chunks_a);
         it_b = item / nchunks; it_chunk = item - it_b * nchunks;
