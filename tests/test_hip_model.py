@@ -545,6 +545,62 @@ def test_kernel_families_give_the_same_gradients_at_bench_size(mm, tmp_path):
                     close(got[k], ref[k], tol=5e-5, what=f"{workload} {tag}: {k} vs default")
 
 
+@pytest.mark.parametrize("case", ["h128_b5_ragged", "h128_b5_masked_skip", "h256_b17_dropout", "config2_b33", "config2_b64_tgt7"])
+def test_persistent_decoder_forward_matches_the_launched_loop(mm, case):
+    """csrc/persist_dec.hip: the decoder's forward time loop as one persistent launch against the same loop as five
+    launches per token (the descriptor without its persist_ws), in ONE process on the same trainer: every tensor the
+    loop leaves behind — attention weights, contexts, gate activations, h / c of every (layer, token), the dropped copies
+    — and the logits.  Shapes: the smallest width taken (128), 256, the bench width; ragged target / context / frame
+    lengths; the reference's masking mode with zero rows skipped; dropout live (same Philox streams in both forms)."""
+    from mmqg_amd import _lib
+    from mmqg_amd.synthetic import WORKLOADS, Workload, build_models, synthetic_batch
+    kw = {}
+    if case.startswith("h128"):
+        w = Workload(case, batch=5, n_frames=4, frame_dim=24, audio_dim=16, ctx_len=7, tgt_len=6, vocab=50, emb_dim=12,
+                     hidden=128, layers=3, video_hidden=128, text_max_length=21, av_max_length=9, dropout=0.0)
+        if case.endswith("masked_skip"):
+            kw = dict(mask_mode=1, skip_zero_value_rows=True)
+    elif case.startswith("h256"):
+        w = Workload(case, batch=17, n_frames=5, frame_dim=40, audio_dim=32, ctx_len=9, tgt_len=5, vocab=70, emb_dim=20,
+                     hidden=256, layers=3, video_hidden=192, text_max_length=40, av_max_length=12, dropout=0.3)
+    else:
+        c2 = WORKLOADS["config2"]
+        w = Workload(**{**c2.dict(), "name": case, "batch": 33 if case.endswith("b33") else 64,
+                        "tgt_len": 7 if case.endswith("tgt7") else 4, "vocab": 500})
+    vid, text, dec = build_models(w, "cuda", seed=11)
+    batch = synthetic_batch(w, seed=23, ragged=True)
+    tr = _trainer(mm, vid, text, dec, batch, seed=77, **kw).train()
+    lib = _lib.load()
+    assert tr.d_dec.persist_ws, f"{case}: the library did not take this shape for the persistent decoder loop"
+    keys = ("attn", "ctx", "gates_d", "hs_d", "cs_d", "hdrop_d")
+    keys = tuple(k for k in keys if k in tr.ws)
+
+    def run():
+        n0 = lib.mmqg_decoder_persist_launch_count()
+        logits = tr.forward_only(batch, training=True).clone()
+        torch.cuda.synchronize()
+        tr.check_health(sync=True)
+        return lib.mmqg_decoder_persist_launch_count() - n0, logits, {k: tr.ws[k].clone() for k in keys}
+
+    n, logits_p, got = run()
+    assert n == 1, "the persistent launch did not run"
+    pws, pwb = tr.d_dec.persist_ws, tr.d_dec.persist_ws_bytes
+    tr.d_dec.persist_ws, tr.d_dec.persist_ws_bytes = None, 0
+    try:
+        n, logits_l, want = run()
+    finally:
+        tr.d_dec.persist_ws, tr.d_dec.persist_ws_bytes = pws, pwb
+    assert n == 0
+    S = tr.S
+    for k in keys:
+        a, b = got[k], want[k]
+        if k == "attn":                       # (columns S .. ldS-1 are padding nobody reads)
+            a, b = a[..., :S], b[..., :S]
+        close(a, b, tol=2e-5, what=f"{case}: {k} of the persistent loop vs launches")
+    close(logits_p, logits_l, tol=2e-5, what=f"{case}: logits")
+    assert float(got["hs_d"].abs().max()) > 0
+
+
 def test_skipping_zero_padded_value_rows_changes_nothing(mm):
     """skip_zero_value_rows: the attention kernels stop at each question's context length / frame count instead of
     streaming the zero padding up to 283 / 101 rows — loss and every gradient must come out the same."""
