@@ -601,6 +601,47 @@ def test_persistent_decoder_forward_matches_the_launched_loop(mm, case):
     assert float(got["hs_d"].abs().max()) > 0
 
 
+def test_a_failed_persistent_decoder_launch_is_loud(mm):
+    """The decoder's persistent forward launch whose device-wide barrier cannot complete (test hook: it waits for one
+    workgroup more than the grid has, with a short spin bound) must not hang and must not pass silently: every
+    workgroup leaves the token loop, the top layer's last state is poisoned with NaN (so the logits and the loss are),
+    the health word is set and the trainer's check raises; after mmqg_persist_clear_failures() the same trainer works."""
+    from mmqg_amd import _lib
+    from mmqg_amd.synthetic import Workload, build_models, synthetic_batch
+    w = Workload("fault", batch=5, n_frames=4, frame_dim=24, audio_dim=16, ctx_len=7, tgt_len=6, vocab=50, emb_dim=12,
+                 hidden=128, layers=3, video_hidden=128, text_max_length=21, av_max_length=9, dropout=0.0)
+    vid, text, dec = build_models(w, "cuda", seed=11)
+    batch = synthetic_batch(w, seed=23, ragged=True)
+    tr = _trainer(mm, vid, text, dec, batch, seed=77).train()
+    lib = _lib.load()
+    assert tr.d_dec.persist_ws
+    good = tr.forward_only(batch, training=True).clone()
+    tr.check_health(sync=True)
+    assert bool(torch.isfinite(good).all())
+    # only the decoder's launch gets the fault: the encoders run on the launch-per-diagonal path for this call
+    saved = [(d, d.persist_ws, d.persist_ws_bytes) for d in (tr.d_text, tr.d_vid)]
+    for d, _, _ in saved:
+        d.persist_ws, d.persist_ws_bytes = None, 0
+    try:
+        lib.mmqg_persist_set_test_fault(1, 2048)
+        n0 = lib.mmqg_decoder_persist_launch_count()
+        bad = tr.forward_only(batch, training=True).clone()
+        torch.cuda.synchronize()
+        assert lib.mmqg_decoder_persist_launch_count() == n0 + 1
+        assert lib.mmqg_persist_failures() > 0, "a timed-out barrier must reach the host"
+        assert not bool(torch.isfinite(bad).all()), "the failed launch must poison its output"
+        with pytest.raises(_lib.BackendError, match="timed out"):
+            tr.check_health(sync=True)
+    finally:
+        lib.mmqg_persist_set_test_fault(0, 0)
+        lib.mmqg_persist_clear_failures()
+        for d, ws, n in saved:
+            d.persist_ws, d.persist_ws_bytes = ws, n
+    again = tr.forward_only(batch, training=True)
+    tr.check_health(sync=True)
+    assert torch.equal(again, good)
+
+
 def test_skipping_zero_padded_value_rows_changes_nothing(mm):
     """skip_zero_value_rows: the attention kernels stop at each question's context length / frame count instead of
     streaming the zero padding up to 283 / 101 rows — loss and every gradient must come out the same."""
