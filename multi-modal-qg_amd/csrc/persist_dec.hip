@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
     if (wg_s) { wbs = wtotal; wtotal += nchs * 64; }
     f32x4* scratch = lds + wtotal;                                   // [kWaves][64]
     float* att_e = reinterpret_cast<float*>(scratch + kWaves * 64);  // [7][kMaxSeg]
-    f32x4* att_comb = reinterpret_cast<f32x4*>(att_e + 7 * kMaxSeg); // [4][16] partial contexts of split text items
+    f32x4* att_comb = reinterpret_cast<f32x4*>(att_e + 7 * kMaxSeg); // [6][16] partial contexts of the later waves of split items
     if (tid < 64) lds[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- weights -> LDS in fragment order: chunk c, lane (i = lane & 15: output column, kq = lane >> 4): 4 consecutive k
@@ -236,22 +236,31 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hB : 0.f), rs, hoff(2, -1) + ((unit * kRows + row) * 4 + q) * 4, 0, 16);
     }
 
-    // ---- attention-phase roles: waves 1-4 = two text items (two waves each: rows halved), waves 5-6 = two video items,
+    // ---- attention-phase roles: waves 1-4 = two text items (two waves each: rows halved; ONE item over all four waves when the batch
+    // has no more than one per workgroup), waves 5-6 = two video items (or one, rows halved),
     // wave 7 = one audio item (32 columns); wave 0, whose lane 0 polls the barriers, has none (its first poll would wait
     // for the value rows it had in flight).  Item lists are question-major and a workgroup's two items of a kind lie G apart, so that the items of any batch
     // spread evenly over the CUs;
     // the host only takes shapes whose items fit one round (2 text + 2 video + 1 audio item per workgroup).
     const int chunks_t = (a.v.H + 63) / 64, chunks_v = (a.v.Dv + 63) / 64, chunks_a = (a.v.Da + 31) / 32;
-    int it_mod = -1, it_half = 0, it_nhalf = 1, it_b = 0, it_chunk = 0;
+    int it_mod = -1, it_half = 0, it_nhalf = 1, it_b = 0, it_chunk = 0;      // (it_half of it_nhalf: this wave's share of the item's rows)
     {
         int item = 0;
-        if (wave >= 1 && wave <= 4) { item = g + ((wave - 1) >> 1) * a.G; it_half = (wave - 1) & 1; it_nhalf = 2; if (item < B * chunks_t) it_mod = 0; }
-        else if (wave == 5 || wave == 6) { item = g + (wave - 5) * a.G; if (item < B * chunks_v) it_mod = 2; }
+        if (wave >= 1 && wave <= 4) {
+            // small batches (one text item per workgroup at most): all four text waves share it, a quarter of the rows each
+            if (B * chunks_t <= a.G) { item = g; it_half = wave - 1; it_nhalf = 4; }
+            else { item = g + ((wave - 1) >> 1) * a.G; it_half = (wave - 1) & 1; it_nhalf = 2; }
+            if (item < B * chunks_t) it_mod = 0;
+        }
+        else if (wave == 5 || wave == 6) {
+            if (B * chunks_v <= a.G) { item = g; it_half = wave - 5; it_nhalf = 2; }
+            else { item = g + (wave - 5) * a.G; }
+            if (item < B * chunks_v) it_mod = 2;
+        }
         else if (wave == 7) { item = g; if (item < B * chunks_a) it_mod = 1; }
         const int nchunks = it_mod == 0 ? chunks_t : (it_mod == 2 ? chunks_v : chunks_a);
         it_b = item / nchunks; it_chunk = item - it_b * nchunks;
     }
-    const int comb_slot = (wave - 1) >> 1;          // text items: where the second wave leaves its partial context
 
     gb::Ctx bar;
     bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
@@ -366,11 +375,11 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
                     acc0.z += __shfl_xor(acc0.z, off, 64); acc0.w += __shfl_xor(acc0.w, off, 64);
                 }
                 part = acc0;
-                if (it_nhalf == 2 && it_half == 1 && lane < 16) att_comb[comb_slot * 16 + lane] = part;
+                if (it_half > 0 && lane < 16) att_comb[(wave - 1) * 16 + lane] = part;       // (waves 2..6)
             }
             __syncthreads();                       // (every wave, with or without an item)
             if (it_mod >= 0 && it_half == 0 && lane < lanes && col_ok) {
-                if (it_nhalf == 2) part += att_comb[comb_slot * 16 + lane];
+                for (int k = 1; k < it_nhalf; ++k) part += att_comb[(wave - 1 + k) * 16 + lane];
                 part = part * inv;
                 *reinterpret_cast<f32x4*>(a.ctx + ((int64_t)t * B + it_b) * Cw + ctx_off + col) = part;      // saved for backward
                 stx(rs, cxoff(t) + (((ctx_off + col) >> 2) * kRows + it_b) * 16, part);                        // operand of layer 0
@@ -481,7 +490,7 @@ WsLayout ws_layout(int T, int H, int Cw, int ldS) {
 int lds_need(int H, int Cw) {
     const int l0 = ((Cw + H) / 16 + H / 16) * 1024;             // layer-0 unit + a score tile
     const int l12 = 2 * (2 * H / 16) * 1024;
-    return 1024 + std::max(l0, l12) + kWaves * 1024 + 7 * kMaxSeg * 4 + 4 * 16 * 16;
+    return 1024 + std::max(l0, l12) + kWaves * 1024 + 7 * kMaxSeg * 4 + 6 * 16 * 16;
 }
 
 }  // namespace
