@@ -931,4 +931,9 @@ def test_bench_self_launch_runs_a_rank_through_rccl(mm):
     assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, "stdout must hold the JSON line only (RCCL's banner goes to stderr)"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["world_size"] == 1 and "nccl" in d["config"]["collective_backend"]
-    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["roofline"]["achieved_beyond_mall"] > 0
+    roof = d["roofline"]
+    assert d["value"] > 0 and roof["frac"] > 0 and roof["bound"] == "hbm" and roof["peak"] == 8000.0
+    # config 2 runs the decoder's forward loop as one persistent launch: the roofline object is its attention phase,
+    # the whole launch and the standalone attention kernel (incl. its beyond-the-Infinity-Cache figure) sit beside it
+    assert roof["whole_launch"]["us_per_launch"] > 0 and roof["whole_launch"]["tokens_per_launch"] == 20
+    assert roof["standalone_kernel"]["achieved_beyond_mall"] > 0 and roof["standalone_kernel"]["frac_back_to_back"] > 0
