@@ -331,8 +331,10 @@ __global__ __launch_bounds__(KS * 64, (MODE == MODE_FWD_CELL && KS == 4) ? 6 : (
 // a thread finishes two (row, unit) pairs: sum of the k-slices + hoisted pre-activations + biases -> cell update.
 constexpr int kWideRows = 64, kWideUnits = 8;
 
-__global__ __launch_bounds__(256, 1) void cell_fwd_wide_kernel(SkinnyBatch batch) {
-    __shared__ float part[4][kWideRows][33];
+// NW waves share a tile's K
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void cell_fwd_wide_kernel(SkinnyBatch batch) {
+    __shared__ float part[NW][kWideRows][33];
     const SkinnyK& a = batch.job[blockIdx.z];
     const int m0 = blockIdx.y * kWideRows, n0 = blockIdx.x * kWideUnits;
     if (m0 >= a.M || n0 >= a.H) return;       // jobs of one launch may differ in size
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void cell_fwd_wide_kernel(SkinnyBatch batch
     for (int r = 0; r < 4; ++r) ra[r] = min(m0 + 16 * r + lr, a.M - 1);
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) nb[cc] = (lr >> 2) * H + min(n0 + 4 * cc + (lr & 3), H - 1);
-    const int per = (a.chunks + 3) / 4;
+    const int per = (a.chunks + NW - 1) / NW;
     const int q0 = wave * per, q1 = min(a.chunks, q0 + per);
     f32x4 acc[4][2];
 #pragma unroll
@@ -438,8 +440,8 @@ __global__ __launch_bounds__(256, 1) void cell_fwd_wide_kernel(SkinnyBatch batch
             for (int e = 0; e < 4; ++e) part[wave][16 * r + 4 * kq + e][16 * cc + c] = acc[r][cc][e];
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int pp = threadIdx.x + 256 * it;
+    for (int it = 0; it < 8 / NW; ++it) {
+        const int pp = threadIdx.x + 64 * NW * it;
         const int row = pp >> 3, u = pp & 7;
         const int b = m0 + row, j = n0 + u;
         if (b >= a.M || j >= H) continue;
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(256, 1) void cell_fwd_wide_kernel(SkinnyBatch batch
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v = part[0][row][cb + 4 * g] + part[1][row][cb + 4 * g] + part[2][row][cb + 4 * g] + part[3][row][cb + 4 * g];
+            if (NW == 8) v += part[4 % NW][row][cb + 4 * g] + part[5 % NW][row][cb + 4 * g] + part[6 % NW][row][cb + 4 * g] + part[7 % NW][row][cb + 4 * g];
             if (a.gates_has_pre) v += grow[g * H + j];
             if (a.bias1) v += a.bias1[g * H + j];
             if (a.bias2) v += a.bias2[g * H + j];
@@ -891,8 +894,9 @@ int try_wide_bwd(const SkinnyBatch& b0, int njobs, hipStream_t s, const char* wh
     const int tiles_m = mmqg::ceil_div(maxM, kBwRows), tiles_n = mmqg::ceil_div(maxN, kBwCols);
     // k slices: enough workgroups for two per CU, at least 32 k-chunks (512 k) per slice
     static const int max_ksl = [] { const char* e = getenv("MMQG_WIDE_MAX_KSL"); return e ? atoi(e) : 4; }();
+    static const int target_wgs = [] { const char* e = getenv("MMQG_WIDE_TARGET_WGS"); return e ? atoi(e) : 256; }();
     int ksl = 1;
-    while (ksl < max_ksl && tiles * ksl < 512 && min_chunks / (2 * ksl) >= 32) ksl *= 2;
+    while (ksl < max_ksl && tiles * ksl < target_wgs && min_chunks / (2 * ksl) >= 32) ksl *= 2;
     const int64_t need = wide_ws_need(njobs, tiles_m, tiles_n, ksl);
     if (need < 0 || need > t_wide_bytes || !mmqg::aligned16(t_wide_ws)) return 1;
     SkinnyBatch b = b0;
@@ -932,7 +936,9 @@ int launch_skinny_batch(const SkinnyBatch& b, int njobs, hipStream_t s, const ch
             wx = std::max(wx, tx); wy = std::max(wy, ty);
         }
         if (ok && wide_wgs >= 192) {
-            hipLaunchKernelGGL(cell_fwd_wide_kernel, dim3(wx, wy, njobs), dim3(256), 0, s, b);
+            // (eight waves per tile for single-job launches — one workgroup per CU — measured slower: config 5 21.62-21.68
+            // against 21.28-21.38 ms)
+            hipLaunchKernelGGL(cell_fwd_wide_kernel<4>, dim3(wx, wy, njobs), dim3(256), 0, s, b);
             return mmqg::check_launch(what);
         }
     }
