@@ -3,20 +3,26 @@
 // need h_top(t-1), the contexts need the scores, layer 0 needs the contexts, layer 1 needs layer 0, layer 2 needs layer
 // 1 — so there is no wavefront over (layer, time) as in the text encoder: the launch has FIVE phases per token, each
 // closed by the fence-free device-wide barrier of grid_barrier.h:
-//   S    scores(t) = hoisted half + h_top(t-1) W_attn[:, E:]^T      31 workgroups x 4 waves, one 16 x 16 MFMA tile each
-//   ATT  three softmaxes + three contexts (the 54 MB value stream)     every CU: 7 waves, one (question, modality,
-//                                                                       64-column chunk) item per wave (text items: two
-//                                                                       waves, rows halved, partials combined through LDS)
+//   S    scores(t) = hoisted half + h_top(t-1) W_attn[:, E:]^T      tiles of 16 score columns, each on up to 4 workgroups
+//                                                                    (16 questions each), K split over the 8 waves
+//   ATT  three softmaxes + three contexts (the 54 MB value stream)  every CU: waves 1-7, one (question, modality, 64-column
+//                                                                    chunk) item per wave or per 2 / 4 waves (rows split,
+//                                                                    partials combined through LDS); the first 16 KB of a
+//                                                                    wave's value rows are issued while the S barrier turns
 //   L0   gates_0 = hoisted half + [ctx(t) | h_0(t-1)] [W_ih0c | W_hh0]^T -> cell     workgroups 0 .. H/4-1
 //   L1   [h_0(t) | h_1(t-1)] -> cell                                                  workgroups H/4 .. H/2-1
 //   L2   [h_1(t) | h_2(t-1)] -> cell                                                  the same workgroups
+// The RECURRENT half of every layer product (h_l(t-1) W_hh_l^T) is formed ahead, in a window in which the workgroup would
+// only wait (layer 1's while layer 0 runs, layer 2's behind the attention barrier, layer 0's — for the next token —
+// while layer 1 runs), and kept in registers: a layer phase carries only the operand that really is late.
 // What the launches pay per token and this kernel does not: the recurrent weights (31 MB at config 2) stay in LDS for
 // the whole sequence — the attention's 54 MB per token flush the 32 MB of L2, so every layer-step LAUNCH re-fetches its
 // 8-13 MB of weights from the Infinity Cache — and the argument fetch / drain of five launches.  What it pays instead:
-// five barriers per token (2.3 us each + store acknowledgement + arrival skew) and only H/4 = 128 of the 256 CUs working
-// in a layer phase (an output-stationary unit of 16 gate columns x K <= 1664 is 64-106 KB: one or two per CU).
-// Exchange data (h of every layer, its dropped copy, the contexts, the scores) is stored write-through (sc1) and loaded
-// sc1, as in persist.hip; c and h of a unit's rows live in registers for the whole sequence.
+// five barriers per token (2.5 us each + store acknowledgement + one load round) and only H/4 = 128 of the 256 CUs
+// working in a layer phase (an output-stationary unit of 16 gate columns x K <= 1664 is 64-106 KB: one or two per CU).
+// Exchange data (h of every layer, its dropped copy, the contexts, the scores) has ONE SLOT PER TOKEN: it is stored
+// write-through (sc1) once and only read after the barrier behind its production, so plain cached loads cannot see an
+// older copy.  c and h of a unit's rows live in registers for the whole sequence.  Measurements: DESIGN.md sections 4, 8.
 #include <stdlib.h>
 
 #include <algorithm>
