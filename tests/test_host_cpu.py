@@ -42,7 +42,7 @@ def test_ctypes_structs_match_the_c_layout(lib_mod, tmp_path):
                                             "persist_ws", "persist_ws_bytes"]),
               "mmqg_lstm_seq_grad": ("LstmSeqGrad", ["dy", "dgates", "lddx", "db_hh", "dc0", "phase"]),
               "mmqg_decoder_seq": ("DecoderSeq", ["values", "xemb", "b_hh", "w_ihT", "w_attn_hT", "seed_offset", "scores",
-                                                  "ld_attn", "hdrop", "phase", "h0_stride_l"]),
+                                                  "ld_attn", "hdrop", "phase", "h0_stride_l", "attn_ws", "persist_ws", "persist_ws_bytes"]),
               "mmqg_decoder_seq_grad": ("DecoderSeqGrad", ["dhtop", "ld_ds", "dxemb", "db_hh", "n_text_rows", "dvideo_stride_b", "phase", "dh_pre"]),
               "mmqg_decoder_decode": ("DecoderDecode", ["values", "emb_table", "b_hh", "w_out", "start_id", "seed", "target",
                                                         "ids", "ld_attn", "xemb", "hs", "logits", "keep_logits"]),
