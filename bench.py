@@ -90,13 +90,35 @@ def self_launch_needed(gpus: int, env) -> bool:
     return (gpus > 1 or env.get("MMQG_BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in env
 
 
+def descendants(pid: int):
+    """Every live descendant of pid (exact PIDs), from /proc: the launcher's ranks sit in sessions of their own, so a
+    process-group kill would miss them."""
+    kids = {}
+    for name in os.listdir("/proc"):
+        if not name.isdigit():
+            continue
+        try:
+            with open(f"/proc/{name}/stat") as f:
+                ppid = int(f.read().rsplit(")", 1)[1].split()[1])
+        except (OSError, ValueError, IndexError):
+            continue
+        kids.setdefault(ppid, []).append(int(name))
+    out, todo = [], [pid]
+    while todo:
+        for c in kids.get(todo.pop(), []):
+            out.append(c)
+            todo.append(c)
+    return out
+
+
 def self_launch(a, argv) -> int:
     """Start the N ranks as a child process tree.  Nothing in this process has touched the GPU yet
     (``import torch`` and ``device_count`` do not), and this process never execs: it waits for the
     launcher and hands its exit code on.  Fails fast with a one-line reason and a non-zero exit code when the node
     has fewer devices than ranks, when any rank dies (the launcher then tears the others down) or when the ranks do
     not finish within --launch-timeout seconds (a rank stuck in rendezvous or in a collective)."""
-    have = int(os.environ.get("MMQG_BENCH_FAKE_DEVICES", "0")) or torch.cuda.device_count()
+    testing = os.environ.get("MMQG_BENCH_TESTING") == "1"         # the test hooks below work only with this set
+    have = (int(os.environ.get("MMQG_BENCH_FAKE_DEVICES", "0")) if testing else 0) or torch.cuda.device_count()
     if have < a.gpus:
         print(f"bench.py: FAILED: --gpus {a.gpus} but this node shows {have} device(s)", file=sys.stderr)
         return 2
@@ -110,18 +132,16 @@ def self_launch(a, argv) -> int:
     except subprocess.TimeoutExpired:
         import signal
         # the launcher puts every rank into a session of its own: collect the whole tree (exact PIDs) before killing
-        victims = [proc.pid]
-        try:
-            import psutil
-            victims += [c.pid for c in psutil.Process(proc.pid).children(recursive=True)]
-        except Exception:
-            pass
+        victims = [proc.pid] + descendants(proc.pid)
         for pid in reversed(victims):
             try:
                 os.kill(pid, signal.SIGKILL)
             except ProcessLookupError:
                 pass
         proc.wait()
+        left = [p for p in victims if os.path.exists(f"/proc/{p}")]
+        if left:
+            print(f"bench.py: processes still alive after SIGKILL: {left}", file=sys.stderr)
         print(f"bench.py: FAILED: the {a.gpus} ranks did not finish within {a.launch_timeout:.0f} s (a rank stuck in rendezvous "
               f"or in a collective); the launcher and its ranks were killed", file=sys.stderr)
         return 3
@@ -541,16 +561,19 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"bench.py: FAILED: --gpus {a.gpus} but WORLD_SIZE={world}")
-    if os.environ.get("MMQG_BENCH_TEST_RANK_FAIL") == str(rank):      # test hook: this rank dies before it touches the GPU
-        raise SystemExit(17)
-    if "MMQG_BENCH_TEST_RANK_HANG" in os.environ:                      # test hook: ranks that never finish
-        time.sleep(3600)
+    if os.environ.get("MMQG_BENCH_TESTING") == "1":                    # test hooks (tests/test_host_cpu.py): off in product runs
+        if os.environ.get("MMQG_BENCH_TEST_RANK_FAIL") == str(rank):      # this rank dies before it touches the GPU
+            raise SystemExit(17)
+        if os.environ.get("MMQG_BENCH_TEST_RANK_HANG") == "1":            # ranks that never finish
+            time.sleep(3600)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_pg = world > 1 or (os.environ.get("MMQG_FORCE_DP") == "1" and "RANK" in os.environ)
     backend = None
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from mmqg_amd.distributed import configure_rccl_env
+        configure_rccl_env()           # RCCL's channel count fits the CUs the persistent backward leaves free
         torch.distributed.init_process_group("nccl", device_id=dev)
         backend = f"{torch.distributed.get_backend()} (RCCL)"
         if torch.distributed.get_world_size() != world:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMQG_ABI_VERSION 9
+#define MMQG_ABI_VERSION 10
 #define MMQG_MAX_LAYERS 8
 
 typedef void* mmqg_stream; /* hipStream_t */
@@ -284,8 +284,18 @@ int mmqg_persist_declined_count(void);
 int mmqg_persist_failures(void);
 int mmqg_persist_clear_failures(void);
 /* test hook: the following persistent launches wait for extra_workgroups more arrivals than their grid has and give up
- * after max_spins polls (0, 0 switches it off) — exercises the failure path without occupying the chip */
+ * after max_spins polls (0, 0 switches it off) — exercises the failure path without occupying the chip.  Refused
+ * (returns -1) unless the process was started with MMQG_ENABLE_TEST_HOOKS=1: a product process cannot arm it. */
 int mmqg_persist_set_test_fault(int extra_workgroups, uint32_t max_spins);
+/* Data-parallel runs: a persistent launch needs ALL its workgroups resident, and an RCCL channel kernel that waits for
+ * a slow peer holds its CUs meanwhile.  The persistent launches that can overlap a collective (the text encoder's
+ * backward time loop: the first gradient buckets travel beside it) therefore size their grid to the usable CUs minus
+ * n; the caller caps RCCL's channels to match (NCCL_MAX_NCHANNELS).  Launches that never overlap a collective (every
+ * forward loop, the decoder's backward loop: no bucket is final before they end) keep the whole chip.  0 = off. */
+int mmqg_persist_set_reserved_cus(int n);
+/* CUs a persistent launch on `stream` would count on: the device's, or fewer under a CU mask of the stream
+ * (hipExtStreamCreateWithCUMask) or of the process (ROC_GLOBAL_CU_MASK); shrinkable != 0: minus the reserve above */
+int mmqg_persist_usable_cus(mmqg_stream stream, int shrinkable);
 /* diagnostics: the following persistent launches write 4 wall-clock stamps (100 MHz) per (workgroup, diagonal) into
  * buf[words] (start, products done, cell done, barrier passed); NULL switches it off.  Stamped launches run a
  * separate instantiation of the kernel: the product kernel carries no stamps. */

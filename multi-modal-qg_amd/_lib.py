@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmmqg_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_LAYERS = 8
 
 K_MAJOR, MN_MAJOR = 0, 1
@@ -187,6 +187,8 @@ SIGNATURES = {
     "mmqg_persist_failures": [],
     "mmqg_persist_clear_failures": [],
     "mmqg_persist_set_test_fault": [C.c_int, C.c_uint32],
+    "mmqg_persist_set_reserved_cus": [C.c_int],
+    "mmqg_persist_usable_cus": [c_f, C.c_int],
     "mmqg_persist_set_trace": [c_f, c_i64],
     "mmqg_lstm_seq_bwd": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],
     "mmqg_lstm_seq_bwd_pair": [C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), C.POINTER(LstmSeq), C.POINTER(LstmSeqGrad), c_f],

@@ -13,8 +13,9 @@ namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, double lr,
                                                    double b1d, double b2d, float eps, const int32_t* __restrict__ step,
-                                                   float grad_scale, float omb1, float omb2) {
-    __shared__ float sh[2];
+                                                   float grad_scale, float omb1, float omb2,
+                                                   const unsigned* __restrict__ failed) {
+    __shared__ float sh[3];
     const float b1 = (float)b1d, b2 = (float)b2d;
     if (threadIdx.x == 0) {
         const double t = (double)step[0];
@@ -22,8 +23,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const double bc2 = 1.0 - pow(b2d, t);
         sh[0] = (float)(lr / bc1);     // step size
         sh[1] = (float)sqrt(bc2);              // sqrt of the second-moment correction
+        // a persistent time loop of this step timed out at its barrier (persist_rt.hip): its gradients are NaN-poisoned.
+        // Dropping the update keeps the parameters and both moments intact — the host raises at its next health check
+        // and the run can go on after mmqg_persist_clear_failures() instead of needing a checkpoint restore.  (One lane
+        // per workgroup reads the word: it lives in pinned host memory.)
+        sh[2] = (failed && __hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) ? 1.f : 0.f;
     }
     __syncthreads();
+    if (sh[2] != 0.f) return;
     const float step_size = sh[0], bc2_sqrt = sh[1];
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
@@ -69,7 +76,8 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr
     MMQG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adam_step: buffers must be 16-byte aligned");
     const int64_t blocks = std::min<int64_t>(ceil_div64(n, 1024), 2048);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2,
-                       (float)eps, step, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2));
+                       (float)eps, step, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2),
+                       (const unsigned*)persist_host_fail_word());
     return check_launch("adam_step");
 }
 

@@ -1,5 +1,6 @@
 // extern "C" surface of libmmqg_hip.so: thin, checked forwarding to the launchers.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -197,9 +198,18 @@ int mmqg_persist_failures(void) { return persist_failures(); }
 int mmqg_persist_clear_failures(void) { persist_clear_failures(); return 0; }
 int mmqg_persist_set_test_fault(int extra_workgroups, uint32_t max_spins) {
     MMQG_REQUIRE(extra_workgroups >= 0, "persist_set_test_fault: extra_workgroups must be >= 0");
+    static const bool hooks = [] { const char* e = getenv("MMQG_ENABLE_TEST_HOOKS"); return e && atoi(e) != 0; }();
+    MMQG_REQUIRE(hooks || (extra_workgroups == 0 && max_spins == 0),
+                 "persist_set_test_fault: fault injection is only armed in a process started with MMQG_ENABLE_TEST_HOOKS=1");
     persist_set_test_fault(extra_workgroups, max_spins);
     return 0;
 }
+int mmqg_persist_set_reserved_cus(int n) {
+    MMQG_REQUIRE(n >= 0, "persist_set_reserved_cus: n must be >= 0");
+    persist_set_reserved_cus(n);
+    return 0;
+}
+int mmqg_persist_usable_cus(mmqg_stream stream, int shrinkable) { return persist_usable_cus(S(stream), shrinkable != 0); }
 int mmqg_persist_set_trace(uint64_t* buf, int64_t words) { persist_set_trace(reinterpret_cast<unsigned long long*>(buf), words); return 0; }
 int mmqg_lstm_seq_bwd(const mmqg_lstm_seq* d, const mmqg_lstm_seq_grad* g, mmqg_stream stream) {
     MMQG_REQUIRE(d && g, "mmqg_lstm_seq_bwd: null descriptor");

@@ -170,6 +170,9 @@ void decoder_persist_set_trace(unsigned long long* buf, int64_t words);
 // persist_rt.hip: who may launch a persistent kernel, and how a failed one reaches the host
 void persist_runtime_prepare();
 int persist_device_cus();
+int persist_usable_cus(hipStream_t s, bool can_shrink);   // device CUs, or the stream's / process's CU mask; minus the reserve if can_shrink
+void persist_set_reserved_cus(int n);
+int persist_reserved_cus();
 unsigned* persist_host_fail_word();
 int persist_begin(hipStream_t s);        // 0 = granted, 1 = declined (another persistent launch may be in flight)
 void persist_end(hipStream_t s);

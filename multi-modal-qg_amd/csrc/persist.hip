@@ -465,7 +465,7 @@ int lstm_seq_fwd_persistent(const mmqg_lstm_seq& d, hipStream_t s) {
     if (d.persist_ws_bytes < wl.total || !aligned16(d.persist_ws)) return 1;
     for (int l = 0; l < d.L; ++l)
         if (!aligned16(d.w_hh[l]) || (l > 0 && !aligned16(d.w_ih[l]))) return 1;
-    const int cus = persist_device_cus();
+    const int cus = persist_usable_cus(s, false);      // (never beside a collective: the forward of a step follows its Adam)
     const int G = std::min(cus, kMaxWG);
     if (G < 64) return 1;
     Plan plan;

@@ -525,7 +525,9 @@ int lstm_seq_bwd_persistent(const mmqg_lstm_seq& d, const mmqg_lstm_seq_grad& g,
                 !grads_aligned(*d2, *g2)))
         return 1;
     const int NL = L + (aux ? 1 : 0);
-    const int G = std::min(persist_device_cus(), kMaxWG);
+    // the chunk list is cut for any grid size: in data-parallel runs this launch is the one that overlaps the first two
+    // gradient buckets' all-reduces and leaves the reserved CUs to RCCL's channels (persist_set_reserved_cus)
+    const int G = std::min(persist_usable_cus(s, true), kMaxWG);
     if (G < 64) return 1;
     const int per = chunks_per_wg(NL + L - 1, H, G);
     if (per == 0) return 1;

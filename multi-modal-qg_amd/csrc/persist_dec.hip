@@ -524,6 +524,7 @@ bool decoder_persist_shape_ok(const mmqg_decoder_seq& d) {
     if ((S + 15) / 16 > H / 4) return false;          // the score tiles live on the layer-0 workgroups
     {   // the attention items of a token must fit one round: 2 text + 2 video + 1 audio item per workgroup
         const int G = std::min(persist_device_cus(), 256);
+        // (a CU-masked stream with fewer CUs fails the same test again at launch time: a.G is what the items are laid out over)
         if (d.B * ((v.H + 63) / 64) > 2 * G || d.B * ((v.Dv + 63) / 64) > 2 * G || d.B * ((v.Da + 31) / 32) > G) return false;
     }
     return lds_need(H, Cw) <= kLdsBudget;
@@ -544,8 +545,9 @@ int decoder_seq_fwd_persistent(const mmqg_decoder_seq& d, hipStream_t s) {
     const WsLayout wl = ws_layout(T, H, Cw, d.ld_attn);
     if (wl.sticky - wl.hx >= (int64_t)1 << 31) return 1;
     if (d.persist_ws_bytes < wl.total || !aligned16(d.persist_ws)) return 1;
-    const int G = std::min(persist_device_cus(), 256);
+    const int G = std::min(persist_usable_cus(s, false), 256);
     if (G < 2 * (H / 4)) return 1;
+    if (B * ((v.H + 63) / 64) > 2 * G || B * ((v.Dv + 63) / 64) > 2 * G || B * ((v.Da + 31) / 32) > G) return 1;
     const bool drop = d.training && d.dropout_p > 0.f;
     if (drop && !d.hdrop) return 1;
     const float* ptrs[] = {d.w_attn, d.w_ih[0], d.w_hh[0], d.w_ih[1], d.w_hh[1], d.w_ih[2], d.w_hh[2], d.scores, d.ctx, d.gates,

@@ -15,6 +15,8 @@
 // synchronising; the sequence executors refuse to run once it is set (mmqg_persist_clear_failures() re-arms them).
 #include <stdlib.h>
 
+#include <algorithm>
+#include <atomic>
 #include <mutex>
 
 #include "mmqg_common.h"
@@ -42,8 +44,9 @@ unsigned* g_fail_host = nullptr;        // pinned host word (host address)
 unsigned* g_fail_dev = nullptr;         // the same word as the device sees it
 bool g_fail_tried = false;
 int g_declined = 0;
-int g_extra_wg = 0;
-unsigned g_max_spins = 0;
+std::atomic<int> g_extra_wg{0};
+std::atomic<unsigned> g_max_spins{0};
+std::atomic<int> g_reserved{0};         // CUs a persistent grid that can shrink leaves to collectives (data parallel)
 
 int cur_dev() {
     int d = 0;
@@ -68,7 +71,8 @@ void persist_runtime_prepare() {
     if (!g_fail_tried) {
         g_fail_tried = true;
         void* h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && h) {
+        // portable: one word every device of the process can address (the kernels of any device report through it)
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && h) {
             *reinterpret_cast<volatile unsigned*>(h) = 0u;
             void* dp = nullptr;
             if (hipHostGetDevicePointer(&dp, h, 0) == hipSuccess && dp) {
@@ -96,6 +100,30 @@ int persist_device_cus() {
     persist_runtime_prepare();
     return g_dev[cur_dev()].cus;
 }
+
+// CUs a persistent grid launched on s can count on: the device's, or fewer when the stream (hipExtStreamCreateWithCUMask)
+// or the process (ROC_GLOBAL_CU_MASK / HSA_CU_MASK) is confined to a CU mask — a grid sized from multiProcessorCount
+// would then never become fully resident and stall to its spin bound.  `can_shrink`: the kernel's plan works for any
+// grid size, so it also leaves out the CUs reserved for collectives (persist_set_reserved_cus).  Every launch still
+// checks its workgroup against hipOccupancyMaxActiveBlocksPerMultiprocessor; a kernel that needs more CUs than this
+// returns "not taken" and its caller runs the launch-per-step path.
+int persist_usable_cus(hipStream_t s, bool can_shrink) {
+    int cus = persist_device_cus();
+    uint32_t mask[32] = {};
+    const int words = std::min(32, (cus + 31) / 32);
+    if (words > 0 && hipExtStreamGetCUMask(s, (uint32_t)words, mask) == hipSuccess) {
+        int n = 0;
+        for (int i = 0; i < words; ++i) n += __builtin_popcount(mask[i]);
+        if (n > 0 && n < cus) cus = n;
+    } else {
+        (void)hipGetLastError();
+    }
+    if (can_shrink) cus -= std::min(std::max(g_reserved.load(), 0), cus / 2);
+    return cus;
+}
+
+void persist_set_reserved_cus(int n) { g_reserved.store(n < 0 ? 0 : n); }
+int persist_reserved_cus() { return g_reserved.load(); }
 
 unsigned* persist_host_fail_word() { return g_fail_dev; }
 
@@ -156,10 +184,10 @@ int persist_check_healthy(const char* who) {
 // test hook: the following persistent launches wait for `extra_workgroups` more arrivals than their grid has and
 // give up after `max_spins` polls (0 = the default bound)
 void persist_set_test_fault(int extra_workgroups, unsigned max_spins) {
-    g_extra_wg = extra_workgroups;
-    g_max_spins = max_spins;
+    g_extra_wg.store(extra_workgroups);
+    g_max_spins.store(max_spins);
 }
-int persist_test_extra_wg() { return g_extra_wg; }
-unsigned persist_test_max_spins() { return g_max_spins; }
+int persist_test_extra_wg() { return g_extra_wg.load(); }
+unsigned persist_test_max_spins() { return g_max_spins.load(); }
 
 }  // namespace mmqg

@@ -24,6 +24,24 @@ def exchange_needed(group=None) -> bool:
     return dist.get_world_size(group) > 1 or os.environ.get("MMQG_FORCE_DP", "0") == "1"
 
 
+# A persistent time loop needs every workgroup of its grid resident at once, and an RCCL channel kernel that waits for a
+# slow peer keeps its CUs for as long as it waits.  So in data-parallel runs the one persistent launch that runs BESIDE
+# collectives (the text encoder's backward loop: the decoder and frame-encoder buckets travel meanwhile) leaves
+# RESERVED_CUS compute units out of its grid (mmqg_persist_set_reserved_cus), and RCCL is capped to as many channels
+# (one workgroup each) as fit there with two collectives in flight.  Every other persistent launch (forward loops, the
+# decoder's backward loop) runs when no bucket is final yet and no collective of the previous step is left (Adam has
+# waited for them): they keep the whole chip.
+RESERVED_CUS = int(os.environ.get("MMQG_DP_RESERVE_CUS", "32"))
+
+
+def configure_rccl_env(env=os.environ) -> None:
+    """Call BEFORE init_process_group: cap RCCL's channels so that two concurrent all-reduces fit the reserved CUs.
+    A value the user has set is left alone."""
+    if RESERVED_CUS > 0:
+        env.setdefault("NCCL_MAX_NCHANNELS", str(max(2, RESERVED_CUS // 2)))
+        env.setdefault("NCCL_MIN_NCHANNELS", str(min(4, max(2, RESERVED_CUS // 2))))
+
+
 def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
     """Rank's contiguous slice of a global batch (dim 0 of every tensor is the question index)."""
     B = next(iter(batch.values())).shape[0]

@@ -31,7 +31,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import K_MAJOR, MN_MAJOR, check, ptr
-from .distributed import GradReducer, broadcast_parameters, exchange_needed, trainer_buckets
+from .distributed import RESERVED_CUS, GradReducer, broadcast_parameters, exchange_needed, trainer_buckets
 
 _TEXT_STREAM = 1 << 40
 _DEC_STREAM = 2 << 40
@@ -96,6 +96,8 @@ class BatchedTrainer:
         # is fragile with one such process per GPU; the graphs are cut where buckets become final and the
         # all-reduces are issued between them, outside any capture
         self.distributed = exchange_needed(process_group)
+        # data parallel: the persistent launch that overlaps collectives leaves CUs to RCCL's channels (distributed.py)
+        _lib.load().mmqg_persist_set_reserved_cus(RESERVED_CUS if self.distributed else 0)
         self.use_graph = use_graph
         self._graph = None
         self._cnn_shape, self._cnn_on, self._graph_cnn = None, False, False
@@ -623,9 +625,9 @@ class BatchedTrainer:
 
         # Single GPU: the frame LSTM's backward time loop rides in the text encoder's persistent backward launch (both
         # need only what the decoder's loop has just produced; csrc/persist_bwd.hip) instead of being a chain of eight
-        # launches on the other branch; only its weight gradients stay there.  Data parallel keeps it on the side branch:
-        # there the frame-encoder bucket's all-reduce should start as early as possible.
-        pair = part == "all" and self.chain_first and bool(self.g_text.persist_ws) and \
+        # launches on the other branch; only its weight gradients stay there.  Data parallel (eager and graph alike) keeps
+        # it on the side branch: there the frame-encoder bucket's all-reduce should start as early as possible.
+        pair = part == "all" and self.chain_first and bool(self.g_text.persist_ws) and not self.distributed and \
             os.environ.get("MMQG_NO_BWD_PAIR", "0") != "1"
         pair_done = []
 

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# fault injection into the persistent launches (mmqg_persist_set_test_fault) is refused unless the process says so
+os.environ.setdefault("MMQG_ENABLE_TEST_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:

@@ -230,7 +230,7 @@ def test_bench_launcher_fails_fast_when_a_rank_dies_or_hangs():
     it touches the GPU (test hook) -> the launcher tears the others down, the parent prints ONE `FAILED` line naming the
     reason, no JSON line, non-zero exit code; a launch that does not finish within --launch-timeout is killed."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(MMQG_BENCH_FAKE_DEVICES="2", MMQG_BENCH_TEST_RANK_FAIL="1")
+    env.update(MMQG_BENCH_TESTING="1", MMQG_BENCH_FAKE_DEVICES="2", MMQG_BENCH_TEST_RANK_FAIL="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
@@ -239,7 +239,7 @@ def test_bench_launcher_fails_fast_when_a_rank_dies_or_hangs():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no result line may be printed"
     # a launch that exceeds its time limit is killed with its whole process group
     env.pop("MMQG_BENCH_TEST_RANK_FAIL")
-    env["MMQG_BENCH_TEST_RANK_HANG"] = "0"
+    env["MMQG_BENCH_TEST_RANK_HANG"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline", "--launch-timeout", "20"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 3

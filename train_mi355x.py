@@ -37,6 +37,8 @@ def setup_distributed():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from mmqg_amd.distributed import configure_rccl_env
+        configure_rccl_env()           # RCCL's channels fit the CUs the persistent backward loop leaves free
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     return world, rank, torch.device("cuda", local)
 
