@@ -187,6 +187,13 @@ int mmqg_reduce_sum(const float* x, int n, float* out, mmqg_stream stream);
  * replayed); grads are multiplied by grad_scale first (1/world_size after an all-reduce sum). */
 int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1,
                    double b2, double eps, const int32_t* step, float grad_scale, mmqg_stream stream);
+/* The same with a guard: skip (nullable) is a device int32; when skip[0] != 0 the launch leaves p, m and v untouched.
+ * mmqg_persist_guard_refresh(flag, stream) sets flag[0] = (a persistent time loop of this process has reported a failure,
+ * mmqg_persist_failures() > 0) with ONE device thread, so that the optimizer launches behind it — also inside a replayed
+ * graph, where the host cannot intervene — drop the update of a step whose gradients were poisoned with NaN. */
+int mmqg_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
+                           double eps, const int32_t* step, float grad_scale, const int32_t* skip, mmqg_stream stream);
+int mmqg_persist_guard_refresh(int32_t* flag, mmqg_stream stream);
 int mmqg_counter_add(int32_t* counter, int delta, mmqg_stream stream);
 /* dst[c][r] = src[r][c]: used to keep k-major (transposed) copies of the recurrent weights for
  * the backward time loops; refresh after every optimizer step. */
@@ -382,6 +389,12 @@ typedef struct {
     float* dh_pre;
     float* wide_ws; int64_t wide_ws_bytes;          /* as mmqg_lstm_seq_grad.wide_ws (max_N = the widest product of the
                                                        loop: max(H, H + Da + Dv, ld_attn)) */
+    float* persist_ws; int64_t persist_ws_bytes;    /* optional workspace (mmqg_decoder_seq_bwd_persist_ws_bytes, 16-byte
+                                                       aligned; needs no initial value): the whole backward time loop
+                                                       (phase 1 without the value gradients) then runs as ONE persistent
+                                                       launch when the shape is taken and the transposed weight copies
+                                                       are given (MMQG_NO_PERSIST_DEC_BWD=1 / MMQG_NO_PERSIST=1: never);
+                                                       failure reporting as mmqg_lstm_seq.persist_ws */
 } mmqg_decoder_seq_grad;
 
 /* mmqg_decoder_decode: the free-running decode loop of validate() / evaluate()
@@ -427,6 +440,13 @@ int64_t mmqg_decoder_seq_persist_ws_bytes(const mmqg_decoder_seq* d);
 int mmqg_decoder_persist_launch_count(void);
 int mmqg_decoder_persist_set_trace(uint64_t* buf, int64_t words);
 int mmqg_decoder_seq_bwd(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g, mmqg_stream stream);
+/* bytes of mmqg_decoder_seq_grad.persist_ws for this pair of descriptors (T, B, L, H, values, ld_attn, ld_ds are read);
+ * 0 = the shape is not taken (B > 64, L != 3, H not a multiple of 32 or beyond 512, the three layers' recurrent weights
+ * beyond the chip's LDS, ...) or MMQG_NO_PERSIST_DEC_BWD=1: the backward time loop then runs five launches per token */
+int64_t mmqg_decoder_seq_bwd_persist_ws_bytes(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g);
+/* diagnostics, as mmqg_decoder_persist_launch_count / _set_trace for the backward kernel (16 stamps per (workgroup, token)) */
+int mmqg_decoder_persist_bwd_launch_count(void);
+int mmqg_decoder_persist_bwd_set_trace(uint64_t* buf, int64_t words);
 
 /* ------------------------------------------------------------------------------------------
  * Frame CNN of VideoConvLstmEncoder (encoder.py:40-50,64-67): blocks of 3x3 valid convolution

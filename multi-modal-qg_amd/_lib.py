@@ -95,7 +95,8 @@ class DecoderSeqGrad(C.Structure):
                 ("dw_ih", _PTRS), ("dw_hh", _PTRS), ("db_ih", _PTRS), ("db_hh", _PTRS),
                 ("n_text_rows", C.c_int32), ("dtext", c_f), ("dtext_stride_row", c_i64), ("dtext_stride_b", c_i64),
                 ("n_video_rows", C.c_int32), ("dvideo", c_f), ("dvideo_stride_row", c_i64), ("dvideo_stride_b", c_i64),
-                ("phase", C.c_int32), ("dh_pre", c_f), ("wide_ws", c_f), ("wide_ws_bytes", c_i64)]
+                ("phase", C.c_int32), ("dh_pre", c_f), ("wide_ws", c_f), ("wide_ws_bytes", c_i64),
+                ("persist_ws", c_f), ("persist_ws_bytes", c_i64)]
 
 
 class TransposeJob(C.Structure):
@@ -170,6 +171,8 @@ SIGNATURES = {
     "mmqg_colsum_add": [c_f, c_i, c_i, c_i, c_f, c_f],
     "mmqg_reduce_sum": [c_f, c_i, c_f, c_f],
     "mmqg_adam_step": [c_f, c_f, c_f, c_f, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, c_f, c_fl, c_f],
+    "mmqg_adam_step_guarded": [c_f, c_f, c_f, c_f, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, c_f, c_fl, c_f, c_f],
+    "mmqg_persist_guard_refresh": [c_f, c_f],
     "mmqg_counter_add": [c_f, c_i, c_f],
     "mmqg_transpose_f32": [c_f, c_i, c_i, c_i, c_f, c_i, c_f],
     "mmqg_transpose_f32_batch": [C.POINTER(TransposeJob), c_i, c_f],
@@ -183,6 +186,9 @@ SIGNATURES = {
     "mmqg_decoder_seq_persist_ws_bytes": [C.POINTER(DecoderSeq)],
     "mmqg_decoder_persist_launch_count": [],
     "mmqg_decoder_persist_set_trace": [c_f, c_i64],
+    "mmqg_decoder_seq_bwd_persist_ws_bytes": [C.POINTER(DecoderSeq), C.POINTER(DecoderSeqGrad)],
+    "mmqg_decoder_persist_bwd_launch_count": [],
+    "mmqg_decoder_persist_bwd_set_trace": [c_f, c_i64],
     "mmqg_persist_declined_count": [],
     "mmqg_persist_failures": [],
     "mmqg_persist_clear_failures": [],

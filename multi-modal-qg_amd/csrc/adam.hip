@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, double lr,
                                                    double b1d, double b2d, float eps, const int32_t* __restrict__ step,
                                                    float grad_scale, float omb1, float omb2,
-                                                   const unsigned* __restrict__ failed) {
+                                                   const int32_t* __restrict__ skip) {
     __shared__ float sh[3];
     const float b1 = (float)b1d, b2 = (float)b2d;
     if (threadIdx.x == 0) {
@@ -23,11 +23,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const double bc2 = 1.0 - pow(b2d, t);
         sh[0] = (float)(lr / bc1);     // step size
         sh[1] = (float)sqrt(bc2);              // sqrt of the second-moment correction
-        // a persistent time loop of this step timed out at its barrier (persist_rt.hip): its gradients are NaN-poisoned.
-        // Dropping the update keeps the parameters and both moments intact — the host raises at its next health check
-        // and the run can go on after mmqg_persist_clear_failures() instead of needing a checkpoint restore.  (One lane
-        // per workgroup reads the word: it lives in pinned host memory.)
-        sh[2] = (failed && __hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) ? 1.f : 0.f;
+        // skip[0] != 0 (mmqg_persist_guard_refresh): a persistent time loop of this step timed out at its barrier
+        // (persist_rt.hip) and its gradients are NaN-poisoned.  Dropping the update keeps the parameters and both
+        // moments intact — the host raises at its next health check and the run can go on after
+        // mmqg_persist_clear_failures() instead of needing a checkpoint restore.
+        sh[2] = (skip && skip[0] != 0) ? 1.f : 0.f;
     }
     __syncthreads();
     if (sh[2] != 0.f) return;
@@ -64,12 +64,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 __global__ void counter_add_kernel(int32_t* ctr, int delta) { ctr[0] += delta; }
 
+// flag[0] = has any persistent launch of this process reported a failure (the word in pinned host memory; ONE lane
+// reads it: 2,048 workgroups of the Adam kernel doing so took 0.6 ms per launch)
+__global__ void guard_refresh_kernel(int32_t* flag, const unsigned* host) {
+    flag[0] = (host && __hip_atomic_load(host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) ? 1 : 0;
+}
+
 }  // namespace
 
 namespace mmqg {
 
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps,
-              const int32_t* step, float grad_scale, hipStream_t s) {
+              const int32_t* step, float grad_scale, hipStream_t s, const int32_t* skip) {
     MMQG_REQUIRE(n >= 0, "adam_step: negative length");
     if (n == 0) return 0;
     MMQG_REQUIRE(p && g && m && v && step, "adam_step: null pointer");
@@ -77,8 +83,15 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr
     const int64_t blocks = std::min<int64_t>(ceil_div64(n, 1024), 2048);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2,
                        (float)eps, step, grad_scale, (float)(1.0 - b1), (float)(1.0 - b2),
-                       (const unsigned*)persist_host_fail_word());
+                       skip);
     return check_launch("adam_step");
+}
+
+int persist_guard_refresh(int32_t* flag, hipStream_t s) {
+    MMQG_REQUIRE(flag, "persist_guard_refresh: null pointer");
+    persist_runtime_prepare();
+    hipLaunchKernelGGL(guard_refresh_kernel, dim3(1), dim3(1), 0, s, flag, (const unsigned*)persist_host_fail_word());
+    return check_launch("persist_guard_refresh");
 }
 
 int counter_add(int32_t* ctr, int delta, hipStream_t s) {

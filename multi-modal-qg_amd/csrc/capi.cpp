@@ -170,6 +170,11 @@ int mmqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doub
                    const int32_t* step, float grad_scale, mmqg_stream stream) {
     return adam_step(p, g, m, v, n, lr, b1, b2, eps, step, grad_scale, S(stream));
 }
+int mmqg_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps,
+                           const int32_t* step, float grad_scale, const int32_t* skip, mmqg_stream stream) {
+    return adam_step(p, g, m, v, n, lr, b1, b2, eps, step, grad_scale, S(stream), skip);
+}
+int mmqg_persist_guard_refresh(int32_t* flag, mmqg_stream stream) { return persist_guard_refresh(flag, S(stream)); }
 int mmqg_counter_add(int32_t* counter, int delta, mmqg_stream stream) { return counter_add(counter, delta, S(stream)); }
 int mmqg_transpose_f32(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, mmqg_stream stream) {
     return transpose_f32(src, ld_src, rows, cols, dst, ld_dst, S(stream));
@@ -190,6 +195,11 @@ int64_t mmqg_lstm_seq_bwd_persist_ws_bytes(int T, int B, int L, int H) { return 
 int mmqg_persist_bwd_launch_count(void) { return persist_bwd_launch_count(); }
 int64_t mmqg_decoder_seq_persist_ws_bytes(const mmqg_decoder_seq* d) { return d ? decoder_persist_ws_bytes(*d) : 0; }
 int mmqg_decoder_persist_launch_count(void) { return decoder_persist_launch_count(); }
+int64_t mmqg_decoder_seq_bwd_persist_ws_bytes(const mmqg_decoder_seq* d, const mmqg_decoder_seq_grad* g) {
+    return (d && g) ? decoder_persist_bwd_ws_bytes(*d, g->ld_ds) : 0;
+}
+int mmqg_decoder_persist_bwd_launch_count(void) { return decoder_persist_bwd_launch_count(); }
+int mmqg_decoder_persist_bwd_set_trace(uint64_t* buf, int64_t words) { decoder_persist_bwd_set_trace(reinterpret_cast<unsigned long long*>(buf), words); return 0; }
 int mmqg_decoder_persist_set_trace(uint64_t* buf, int64_t words) { decoder_persist_set_trace(reinterpret_cast<unsigned long long*>(buf), words); return 0; }
 int mmqg_persist_bwd_set_trace(uint64_t* buf, int64_t words) { persist_bwd_set_trace(reinterpret_cast<unsigned long long*>(buf), words); return 0; }
 int64_t mmqg_wide_ws_bytes(int B, int max_N) { return skinny_wide_ws_bytes(B, max_N); }

@@ -167,6 +167,11 @@ int64_t decoder_persist_ws_bytes(const mmqg_decoder_seq& d);
 int decoder_seq_fwd_persistent(const mmqg_decoder_seq& d, hipStream_t s);   // 0 done, 1 not taken, < 0 error
 int decoder_persist_launch_count();
 void decoder_persist_set_trace(unsigned long long* buf, int64_t words);
+// persist_dec_bwd.hip: the backward time loop of the attention decoder as one persistent launch
+int64_t decoder_persist_bwd_ws_bytes(const mmqg_decoder_seq& d, int ld_ds);
+int decoder_seq_bwd_persistent(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, hipStream_t s);   // 0 done, 1 not taken, < 0 error
+int decoder_persist_bwd_launch_count();
+void decoder_persist_bwd_set_trace(unsigned long long* buf, int64_t words);
 // persist_rt.hip: who may launch a persistent kernel, and how a failed one reaches the host
 void persist_runtime_prepare();
 int persist_device_cus();
@@ -193,7 +198,8 @@ int pack_batch(const mmqg_batch_pack& a, hipStream_t s);
 
 // ---- adam.hip -------------------------------------------------------------------------
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps,
-              const int32_t* step, float grad_scale, hipStream_t s);
+              const int32_t* step, float grad_scale, hipStream_t s, const int32_t* skip = nullptr);
+int persist_guard_refresh(int32_t* flag, hipStream_t s);
 int counter_add(int32_t* ctr, int delta, hipStream_t s);
 
 }  // namespace mmqg

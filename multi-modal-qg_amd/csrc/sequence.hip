@@ -563,6 +563,15 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
     const WideWsScope wide_scope(g.wide_ws, g.wide_ws_bytes);
     const bool do_loop = g.phase != 2, do_wgrad = g.phase != 1;
     if (do_loop) {
+    // the whole time loop incl. the initial-state gradients as ONE persistent launch (persist_dec_bwd.hip) where the shape
+    // is taken; the launched loop below otherwise
+    bool loop_done = false;
+    if (g.persist_ws && !g_no_fuse() && d.w_ih0cT && d.w_attn_hT) {
+        const int rc = decoder_seq_bwd_persistent(d, g, s);
+        if (rc < 0) return rc;
+        loop_done = rc == 0;
+    }
+    if (!loop_done) {
     {
         const CopySeg z[2] = {CopySeg{g.dh, nullptr, (int64_t)L * BH}, CopySeg{g.dc, nullptr, (int64_t)L * BH}};
         MMQG_TRY(copy_or_zero_multi(z, 2, s));
@@ -682,6 +691,7 @@ int decoder_seq_bwd(const mmqg_decoder_seq& d, const mmqg_decoder_seq_grad& g, h
             MMQG_TRY(skinny_plain_multi(pj, nj, s));
         }
     }
+    }   // !loop_done
     // gradient of the value rows an encoder produced (text rows feed the text encoder's
     // backward, video rows the frame encoder's); audio features are inputs and get none
     if (g.dtext && g.n_text_rows > 0)

@@ -179,8 +179,11 @@ class BatchedTrainer:
         # two device counters: step_dev = completed steps (mixed into the dropout seed while a step runs, so it may
         # only advance when the step's backward is over); adam_dev = Adam's 1-based step number, advanced before the
         # FIRST optimizer launch of a step (a data-parallel step starts its Adam early, beside the text encoder's backward)
-        self.counters = torch.zeros(2, device=self.dev, dtype=torch.int32)
+        self.counters = torch.zeros(4, device=self.dev, dtype=torch.int32)
         self.step_dev, self.adam_dev = self.counters[0:1], self.counters[1:2]
+        # guard word of the optimizer launches: set on the device (mmqg_persist_guard_refresh) when a persistent time loop
+        # of this step has timed out at its barrier — Adam then leaves parameters and moments alone
+        self.guard_dev = self.counters[2:3]
         self.n_params = total
 
     # ------------------------------------------------------------------------ workspaces
@@ -359,6 +362,11 @@ class BatchedTrainer:
         if n > 0:
             w["dec_pws"] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)
             dd.persist_ws, dd.persist_ws_bytes = w["dec_pws"].data_ptr(), n
+        # ... and its whole BACKWARD time loop (csrc/persist_dec_bwd.hip; round 4): per-token exchange slots, 0.3-0.6 GB
+        n = int(_lib.load().mmqg_decoder_seq_bwd_persist_ws_bytes(C.byref(dd), C.byref(gd)))
+        if n > 0:
+            w["dec_pws_b"] = torch.zeros((n + 3) // 4, device=self.dev, dtype=torch.float32)
+            gd.persist_ws, gd.persist_ws_bytes = w["dec_pws_b"].data_ptr(), n
         self.d_dec, self.g_dec = dd, gd
 
     def _persist_ws(self, d, key):
@@ -774,16 +782,21 @@ class BatchedTrainer:
         split = self._adam_split()
         if part in ("all", "early"):
             check(lib.mmqg_counter_add(self.adam_dev.data_ptr(), 1, s), "counter_add")
+        # one device thread copies the persistent kernels' failure word (pinned host memory) into the guard the optimizer
+        # launches read: a step whose gradients were poisoned is dropped instead of destroying parameters and moments
+        check(lib.mmqg_persist_guard_refresh(self.guard_dev.data_ptr(), s), "persist_guard_refresh")
+        guard = self.guard_dev.data_ptr()
         lo, hi = {"all": (0, self.n_params), "early": (0, split), "late": (split, self.n_params)}[part]
         if hi > lo:
-            check(lib.mmqg_adam_step(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
-                                     self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo, self.lr, b1,
-                                     b2, self.eps, self.adam_dev.data_ptr(), scale, s), "adam_step")
+            check(lib.mmqg_adam_step_guarded(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
+                                             self.flat_m.data_ptr() + 4 * lo, self.flat_v.data_ptr() + 4 * lo, hi - lo,
+                                             self.lr, b1, b2, self.eps, self.adam_dev.data_ptr(), scale, guard, s), "adam_step")
         if part in ("all", "late"):
             e0, e1 = self.segments["emb"]
-            check(lib.mmqg_adam_step(self.flat_p.data_ptr() + 4 * e0, self.flat_g.data_ptr() + 4 * e0,
-                                     self.emb_m2.data_ptr(), self.emb_v2.data_ptr(), e1 - e0, self.lr, b1, b2, self.eps,
-                                     self.adam_dev.data_ptr(), scale, s), "adam_step(embedding, 2nd optimizer)")
+            check(lib.mmqg_adam_step_guarded(self.flat_p.data_ptr() + 4 * e0, self.flat_g.data_ptr() + 4 * e0,
+                                             self.emb_m2.data_ptr(), self.emb_v2.data_ptr(), e1 - e0, self.lr, b1, b2,
+                                             self.eps, self.adam_dev.data_ptr(), scale, guard, s),
+                  "adam_step(embedding, 2nd optimizer)")
             check(lib.mmqg_counter_add(self.step_dev.data_ptr(), 1, s), "counter_add")
 
     def _allreduce(self):

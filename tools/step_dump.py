@@ -70,6 +70,7 @@ def main():
     out["persist_launches"] = np.int64(_lib.load().mmqg_persist_launch_count())
     out["persist_bwd_launches"] = np.int64(_lib.load().mmqg_persist_bwd_launch_count())
     out["decoder_persist_launches"] = np.int64(_lib.load().mmqg_decoder_persist_launch_count())
+    out["decoder_persist_bwd_launches"] = np.int64(_lib.load().mmqg_decoder_persist_bwd_launch_count())
     out["projection_kernel"] = np.int64(_lib.load().mmqg_projection_last_kernel())
     out["persist_declined"] = np.int64(_lib.load().mmqg_persist_declined_count())
     out["persist_failures"] = np.int64(_lib.load().mmqg_persist_failures())
