@@ -158,10 +158,10 @@ __device__ __forceinline__ void reduce_ahead(const Rsrc& rs, int src0, int sstri
     const int half = lane >> 5;
     for (int ob = 0; ob < n_out; ob += 32) {
         const int o = ob + (lane & 31);
-        const int voff = o < n_out ? (o0 + o) * 16 : kOob;
+        const int voff = o < n_out ? (o0 + o) * 16 + half * HALF * sstride : kOob;     // (the lane's half of the slices: per-lane part)
         f32x4 v[HALF];
 #pragma unroll
-        for (int i = 0; i < HALF; ++i) v[i] = ldxs(rs, voff, src0 + (half * HALF + i) * sstride);
+        for (int i = 0; i < HALF; ++i) v[i] = ldxs(rs, voff, src0 + i * sstride);
         f32x4 sum = v[0];
 #pragma unroll
         for (int i = 1; i < HALF; ++i) sum += v[i];
@@ -495,11 +495,13 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             }
             // (the forward's context of this thread's dctx columns: the softmax Jacobian's row dot is ctx . dctx)
             f32x4 cxv = zero4();
-            if (v_need && 4 * tq < v_D)
-                cxv = *reinterpret_cast<const f32x4*>(a.ctx + ((int64_t)t * B + qb) * Cw + v_off + 4 * tq);
+            const float* cxp = a.ctx + ((int64_t)t * B + qb) * Cw + v_off + 4 * tq;
+            const bool cx_on = v_need && 4 * tq < v_D;
+            if (cx_on && wave != 0) cxv = *reinterpret_cast<const f32x4*>(cxp);      // (wave 0 polls: nothing in flight there)
             if (pend) { ok = gb::wait(bar); pend = false; }
             if (!ok) break;
             MMQG_GSTAMP(12)
+            if (cx_on && wave == 0) cxv = *reinterpret_cast<const f32x4*>(cxp);
             // dctx(t)[qb][modality columns] = sum over the slices' row-major partial blocks; 128 threads per modality
             float* dotp = reinterpret_cast<float*>(frag + 3 * 128);       // [8] per-wave parts of ctx . dctx
             if (v_need) {
