@@ -63,6 +63,7 @@ struct DbArgs {
     int tpcL2, tpcL1, tpcL0, tpcA;           // late / ahead column tiles per workgroup
     int nchS, NKR, cpk;                      // score-gradient product: k-chunks, k-ranges, chunks per range
     int cpq, n_t, n_v, n_a;                  // attention plan: workgroups per question, wave-items per modality
+    int dbg;                                 // diagnostics (MMQG_PDB_DBG): 1 = wave 0 never loads ahead of its poll, 2 = no dgates stores (WRONG results)
     mmqg_attn_values v;
     const float* w_ihT1; const float* w_ihT2;                        // [H][4H] k-major copies
     const float* w_hhT0; const float* w_hhT1; const float* w_hhT2;   // [H][4H]
@@ -152,22 +153,36 @@ __device__ __forceinline__ void load_early(Early& e, const Rsrc& rs, const float
 // Sum of the NS slices' partial tiles of an ahead product (dG_l(t) W_hh_l, [H/4 column quads][64 rows][4], contiguous per
 // slice) into the reduced block the cells of token t - 1 read: this workgroup's n_out 16-byte outputs starting at o0, by ONE
 // wave in a window behind a barrier arrival (lane = (output, half of the slices); 8 loads in flight per lane at NS = 16).
-template <int NS, typename Rsrc>
-__device__ __forceinline__ void reduce_ahead(const Rsrc& rs, int src0, int sstride, int dst0, int o0, int n_out, int lane) {
-    constexpr int HALF = NS / 2;
-    const int half = lane >> 5;
-    for (int ob = 0; ob < n_out; ob += 32) {
-        const int o = ob + (lane & 31);
+// In two halves, so that the wave's share of the window's product runs while the loads are in flight.
+template <int NS>
+struct AheadSum {
+    f32x4 v[NS / 2];
+    int o, n_out, dst;
+    template <typename Rsrc>
+    __device__ __forceinline__ void issue(const Rsrc& rs, int src0, int sstride, int dst0, int o0, int ob, int n, int lane) {
+        constexpr int HALF = NS / 2;
+        const int half = lane >> 5;
+        o = ob + (lane & 31); n_out = n; dst = dst0 + (o0 + o) * 16;
         const int voff = o < n_out ? (o0 + o) * 16 + half * HALF * sstride : kOob;     // (the lane's half of the slices: per-lane part)
-        f32x4 v[HALF];
 #pragma unroll
         for (int i = 0; i < HALF; ++i) v[i] = ldxs(rs, voff, src0 + i * sstride);
+    }
+    template <typename Rsrc>
+    __device__ __forceinline__ void finish(const Rsrc& rs, int lane) {
         f32x4 sum = v[0];
 #pragma unroll
-        for (int i = 1; i < HALF; ++i) sum += v[i];
+        for (int i = 1; i < NS / 2; ++i) sum += v[i];
         sum.x += __shfl_xor(sum.x, 32, 64); sum.y += __shfl_xor(sum.y, 32, 64);
         sum.z += __shfl_xor(sum.z, 32, 64); sum.w += __shfl_xor(sum.w, 32, 64);
-        if (half == 0 && o < n_out) stx(rs, dst0 + (o0 + o) * 16, sum);
+        if ((lane >> 5) == 0 && o < n_out) stx(rs, dst, sum);
+    }
+};
+template <int NS, typename Rsrc>
+__device__ __forceinline__ void reduce_ahead(const Rsrc& rs, int src0, int sstride, int dst0, int o0, int n_out, int lane, int ob0 = 0) {
+    for (int ob = ob0; ob < n_out; ob += 32) {
+        AheadSum<NS> r;
+        r.issue(rs, src0, sstride, dst0, o0, ob, n_out, lane);
+        r.finish(rs, lane);
     }
 }
 
@@ -190,8 +205,68 @@ __device__ __forceinline__ void products(const Rsrc& rs, const f32x4* frag, cons
     }
 }
 
+// ---- attention backward of one wave-item: rows [r0, r1) of a question's segment, D floats wide.  A wave's four 16-lane
+// groups take 8 >> LOG rows each per batch, NKP = 1 << LOG 16-byte columns per lane and row (16 lanes x NKP x 16 bytes >= D):
+// every one of the 8 loads a lane has in flight per batch carries data for any width — with one row per group a 128-float
+// audio row used 2 of the 8 loads and its wave ran three times longer than a text wave of the same byte count.
+constexpr int kAttK = kMaxD / 64;        // 8 loads per lane and batch
+template <int LOG, typename Rsrc>
+__device__ __forceinline__ void att_fetch(f32x4 (&dst)[kAttK], const Rsrc& rv, int first, int rg, int cl, int last, int D, int Dq, int oob) {
+    constexpr int NKP = 1 << LOG, RPL = kAttK >> LOG;
+#pragma unroll
+    for (int k = 0; k < kAttK; ++k) {
+        const int kk = k >> LOG, cq = cl + 16 * (k & (NKP - 1));
+        const int r = min(first + rg * RPL + kk, last);
+        dst[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, cq < Dq ? (r * D + 4 * cq) * 4 : oob, 0, 0));
+    }
+}
+template <int LOG>
+__device__ __forceinline__ float att_fetch_a(const float* arow, int first, int rg, int cl, int r1) {
+    constexpr int RPL = kAttK >> LOG;
+    const int r = first + rg * RPL + cl;
+    return (cl < RPL && r < r1) ? arow[r] : 0.f;
+}
+// one batch: d(attn) of 4 * RPL rows from the value rows in `buf`, dS stored.  The dctx columns come from LDS at every use
+// (8 ds_read_b128 per batch at most): kept in registers they cost 32 VGPRs in a kernel that has none to spare.
+template <int LOG>
+__device__ __forceinline__ void att_batch(const f32x4 (&buf)[kAttK], const f32x4* vec, int Dq, float aw, float* dsr, float dot, int r,
+                                          int r1, int n_stream, int rg, int cl) {
+    constexpr int NKP = 1 << LOG, RPL = kAttK >> LOG;
+    float mine = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < RPL; ++kk) {
+        float p = 0.f;
+#pragma unroll
+        for (int k = 0; k < NKP; ++k) p += dot4(buf[kk * NKP + k], vec[min(cl + 16 * k, Dq - 1)]);      // (columns past D: the value loads returned zero)
+        p = sum16(p);
+        mine = cl == kk ? p : mine;
+    }
+    const int ri = r + rg * RPL + cl;
+    if (cl < RPL && ri < r1) {
+        const float da = ri < n_stream ? mine : 0.f;
+        __hip_atomic_store(dsr + ri, aw * (da - dot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through
+    }
+}
+// the row loop of an item: two batches in flight, the buffers take turns (no register copies)
+template <int LOG, typename Rsrc>
+__device__ __forceinline__ void att_stream(f32x4 (&b0)[kAttK], f32x4 (&b1)[kAttK], float a0, float a1, const Rsrc& rv,
+                                           const float* arow, float* dsr, const f32x4* vec, float dot, int r0, int r1, int n_stream,
+                                           int rg, int cl, int last, int D, int Dq, int oob) {
+    constexpr int RPL = kAttK >> LOG, STEP = 4 * RPL;
+    for (int r = r0; r < r1; r += 2 * STEP) {
+        att_batch<LOG>(b0, vec, Dq, a0, dsr, dot, r, r1, n_stream, rg, cl);
+        if (r + 2 * STEP < r1) { att_fetch<LOG>(b0, rv, r + 2 * STEP, rg, cl, last, D, Dq, oob); a0 = att_fetch_a<LOG>(arow, r + 2 * STEP, rg, cl, r1); }
+        if (r + STEP < r1) {
+            att_batch<LOG>(b1, vec, Dq, a1, dsr, dot, r + STEP, r1, n_stream, rg, cl);
+            if (r + 3 * STEP < r1) { att_fetch<LOG>(b1, rv, r + 3 * STEP, rg, cl, last, D, Dq, oob); a1 = att_fetch_a<LOG>(arow, r + 3 * STEP, rg, cl, r1); }
+        }
+    }
+}
+
+// stamps go to LDS (behind the dG fragment; 64 bytes per token) and to memory only when the loop is over: a global store
+// per stamp sat in wave 0's memory queue in front of its loads and changed what it measured
 #define MMQG_GSTAMP(slot)                                                                              \
-    if (TRACE && tid == 0) a.trace[((size_t)blockIdx.x * a.T + t) * kTraceSlots + (slot)] = wall_clock64();
+    if (TRACE && tid == 0) stamps[t * kTraceSlots + (slot)] = (unsigned)wall_clock64();
 
 template <bool TRACE, int NS>
 __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs a) {
@@ -207,6 +282,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     const int red_n = (16 * H + (int)gridDim.x - 1) / (int)gridDim.x, red_o0 = min(16 * H, g * red_n);      // this workgroup's outputs of a reduction
     const int red_cnt = min(red_n, 16 * H - red_o0);
     const bool cellwg = cg < GS;
+    const int dg_rows = (kRows + GS - 1) / GS;          // rows of the gate gradients each of a slice's workgroups stores
     const int nlate21 = H / 16, nlate0 = Cw / 16, nahead = H / 16;
     const int pq = 2 * H / 4;                           // column quads of a P2 / P1 slice block (late | ahead)
 
@@ -214,6 +290,8 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     // attention stage's dctx vectors, the score-gradient stage's k-part combine)
     const int wb2 = 0, wb1 = wb2 + (tpcL2 + tpcA) * 512, wb0 = wb1 + (tpcL1 + tpcA) * 512, wbs = wb0 + (tpcL0 + tpcA) * 512;
     f32x4* frag = lds + wbs + a.cpk * 64;
+    unsigned* stamps = reinterpret_cast<unsigned*>(frag + kFragF4);      // [T][kTraceSlots], stamped instantiation only
+    if (TRACE) for (int i = tid; i < a.T * kTraceSlots; i += kThreads) stamps[i] = 0u;
 
     // my tiles of a layer: late tiles [cg * tpcL, ...) of nlate, ahead tiles [cg * tpcA, ...) of H/16
     const int nL2 = cellwg ? max(0, min(tpcL2, nlate21 - cg * tpcL2)) : 0;
@@ -264,9 +342,6 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     const int RB = a.RB, KP = kWaves / RB;
     const int rb = wave % RB, cp = wave / RB;
     const bool rb_on = rb * 16 < B;
-    // (in the window behind a barrier arrival wave 0 — whose lane 0 polls — does nothing: the other column parts of its
-    // row block take its tiles)
-    const int KPw = rb == 0 ? KP - 1 : KP, cpw = rb == 0 ? cp - 1 : cp;
 
     // ---- attention plan (closed form): question qb = g % B on the cpq workgroups g = qb + B * qq; item k = 7 qq + wave - 1:
     // text parts [0, n_t), video parts [n_t, n_t + n_v), audio parts [n_t + n_v, n_t + n_v + n_a)
@@ -371,7 +446,9 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             const float* cr = a.cs + (((int64_t)l * (T + 1) + t) * B + rowc) * H + u0;
             const float* xr = l == 2 ? a.dhtop + ((int64_t)t * B + rowc) * H + u0 : nullptr;
             const int aoff = t + 1 < T ? tok1 + r_off + l * r_bytes + ((8 * sl + wave) * kRows + row) * 16 : kOob;
-            const bool early_now = cellwg && (wave != 0 || !pend);
+            // (... unless this workgroup arrived last in its XCC: that lane 0 then releases the XCC, and its first poll would
+            // wait for the loads)
+            const bool early_now = cellwg && (wave != 0 || !pend || (!(a.dbg & 1) && !__builtin_amdgcn_readfirstlane((int)bar.leader)));
             if (early_now) load_early(e, rs, gr, cr, xr, H, BH, aoff);
             if (pend) { ok = gb::wait(bar); pend = false; }
             MMQG_GSTAMP(3 + 3 * ph_i)
@@ -437,36 +514,48 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             MMQG_GSTAMP(5 + 3 * ph_i)
             gb::arrive(bar);
             pend = true;
-            // ---- window while the barrier turns: the ahead product dG_l(t) W_hh_l (needed by cell (l, t-1)), then the gate
-            // gradients for the hoisted weight-gradient GEMMs (the slice's first workgroup; wave 1 also stores wave 0's)
-            if (rb_on && wave != 0)
-                products(rs, frag, lds + wb + tpcL * 512 + ln, nA, cpw, KPw, rb, j, q,
-                         tok + pl_off + (sl * a_quads + a_first + 4 * cg * tpcA + q) * 1024 + (rb * 16 + j) * 16, 4 * 1024);
-            // ... and (P0's window) the sum over the slices of layer 2's ahead product of this token for cell (2, t-1): its
-            // tiles were stored in P2's window and drained at the arrival to P1's barrier, which this workgroup has passed
-            if (l == 0 && wave == kWaves - 1 && red_cnt > 0)
-                reduce_ahead<NS>(rs, tok + nlate21 * 4 * 1024, pq * 1024, tok + r_off + 2 * r_bytes, red_o0, red_cnt, ln);
-            if (cellwg && cg == 0 && rvalid && wave != 0) {
-                float* dg = a.dgates + (((int64_t)l * T + t) * B + row) * 4 * H + u0;
-                *reinterpret_cast<f32x4*>(dg) = dG0; *reinterpret_cast<f32x4*>(dg + H) = dG1;
-                *reinterpret_cast<f32x4*>(dg + 2 * H) = dG2; *reinterpret_cast<f32x4*>(dg + 3 * H) = dG3;
-                if (wave == 1) {
-                    dg -= 4;
-                    *reinterpret_cast<f32x4*>(dg) = frag[0 * kRows + row]; *reinterpret_cast<f32x4*>(dg + H) = frag[8 * kRows + row];
-                    *reinterpret_cast<f32x4*>(dg + 2 * H) = frag[16 * kRows + row]; *reinterpret_cast<f32x4*>(dg + 3 * H) = frag[24 * kRows + row];
+            // ---- window while the barrier turns: the ahead product dG_l(t) W_hh_l (needed by cell (l, t-1)); in P0's window
+            // also the sum over the slices of layer 2's ahead product of this token for cell (2, t-1) — its tiles were stored
+            // in P2's window and drained at the arrival to P1's barrier, which this workgroup has passed — by the last wave,
+            // whose loads fly while it multiplies; then the gate gradients for the hoisted weight-gradient GEMMs (every
+            // workgroup of the slice a few rows; wave 1 also stores wave 0's quad)
+            const bool red_on = l == 0 && wave == kWaves - 1 && red_cnt > 0;
+            {
+                // the window's product waves of this row block: not wave 0 (it polls), and in P0's window not the last wave
+                // (it sums); their column parts are renumbered
+                int part = -1, nparts = 0;
+                for (int p = 0; p < KP; ++p) {
+                    const int w = rb + RB * p;
+                    const bool act = w != 0 && !(l == 0 && w == kWaves - 1 && red_cnt > 0);
+                    if (w == wave && act) part = nparts;
+                    nparts += act ? 1 : 0;
+                }
+                if (rb_on && part >= 0)
+                    products(rs, frag, lds + wb + tpcL * 512 + ln, nA, part, nparts, rb, j, q,
+                             tok + pl_off + (sl * a_quads + a_first + 4 * cg * tpcA + q) * 1024 + (rb * 16 + j) * 16, 4 * 1024);
+            }
+            if (red_on) reduce_ahead<NS>(rs, tok + nlate21 * 4 * 1024, pq * 1024, tok + r_off + 2 * r_bytes, red_o0, red_cnt, ln);
+            // the gate gradients for the hoisted weight-gradient GEMMs: every workgroup of the slice stores dg_rows rows, ONE
+            // wave reads them back from the fragment so that 8 lanes cover a whole 128-byte line (32 units of a gate); the
+            // scattered 16-byte stores of the cell lanes took 2-3 us to be acknowledged, in front of the next stage's loads
+            if (cellwg && wave == kWaves - 2 && !(a.dbg & 2)) {
+                for (int idx = ln; idx < dg_rows * 32; idx += 64) {
+                    const int r = cg * dg_rows + (idx >> 5), gt = (idx >> 3) & 3, wq = idx & 7;
+                    if (r < B)
+                        *reinterpret_cast<f32x4*>(a.dgates + (((int64_t)l * T + t) * B + r) * 4 * H + gt * H + kU * sl + 4 * wq) =
+                            frag[(8 * gt + wq) * kRows + r];
                 }
             }
         }
         if (!ok) break;
         // =================================================== ATT: dctx(t) from P0's slices, attention backward -> dS(t)
         {
-            constexpr int kK = kMaxD / 64;           // 16-byte columns per lane
             MMQG_LANE_ROLES
-            f32x4 cur[kK], nxt[kK];
+            f32x4 cur[kAttK], nxt[kAttK];
             float a_cur = 0.f, a_nxt = 0.f;
             const int rg = ln >> 4, cl = ln & 15;
             const int tq = (wave & 1) * 64 + ln;       // index among the 128 threads of a modality's dctx sum
-            int L = 1, D = 4, seg_off = 0, n_stream = 0, oob = 16, last = 0, Dq = 1;
+            int L = 1, D = 4, seg_off = 0, n_stream = 0, oob = 16, last = 0, Dq = 1, lg = 3;
             const float* base = a.v.text;
             if (it_mod >= 0) {
                 int valid;
@@ -475,33 +564,27 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
                 else { base = a.v.video + (int64_t)qb * a.v.video_stride_b; L = a.v.Lav; D = a.v.Dv; seg_off = a.v.Lt + a.v.Lav; valid = a.v.av_len ? a.v.av_len[qb] : L; }
                 n_stream = a.v.zero_past_len ? min(L, valid) : L;
                 oob = L * D * 4; last = max(n_stream - 1, 0); Dq = D / 4;
+                lg = D > 128 ? 3 : 1;       // 16-byte columns per lane and row: 8 (one row per 16-lane group and batch) or 2 (four rows)
             }
             // (the question's value rows through a buffer descriptor: out-of-range offsets read as zero)
             const auto rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, L * D * 4, 0x00020000);
             const float* arow = a.attn + ((int64_t)t * B + qb) * a.ldS + seg_off;
-            if (it_mod >= 0) {         // (waves 1..7: nothing here depends on the chain)
-#pragma unroll
-                for (int k = 0; k < kK; ++k) {
-                    const int cq = cl + 16 * k;
-                    cur[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, cq < Dq ? (min(it_r0 + rg, last) * D + 4 * cq) * 4 : oob, 0, 0));
-                }
-#pragma unroll
-                for (int k = 0; k < kK; ++k) {
-                    const int cq = cl + 16 * k;
-                    nxt[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, cq < Dq ? (min(it_r0 + 4 + rg, last) * D + 4 * cq) * 4 : oob, 0, 0));
-                }
-                a_cur = (cl == 0 && it_r0 + rg < it_r1) ? arow[it_r0 + rg] : 0.f;
-                a_nxt = (cl == 0 && it_r0 + 4 + rg < it_r1) ? arow[it_r0 + 4 + rg] : 0.f;
+            if (it_mod >= 0) {         // (waves 1..7: nothing here depends on the chain) the first two batches of value rows
+                if (lg == 3) { att_fetch<3>(cur, rv, it_r0, rg, cl, last, D, Dq, oob); att_fetch<3>(nxt, rv, it_r0 + 4, rg, cl, last, D, Dq, oob);
+                               a_cur = att_fetch_a<3>(arow, it_r0, rg, cl, it_r1); a_nxt = att_fetch_a<3>(arow, it_r0 + 4, rg, cl, it_r1); }
+                else { att_fetch<1>(cur, rv, it_r0, rg, cl, last, D, Dq, oob); att_fetch<1>(nxt, rv, it_r0 + 16, rg, cl, last, D, Dq, oob);
+                       a_cur = att_fetch_a<1>(arow, it_r0, rg, cl, it_r1); a_nxt = att_fetch_a<1>(arow, it_r0 + 16, rg, cl, it_r1); }
             }
             // (the forward's context of this thread's dctx columns: the softmax Jacobian's row dot is ctx . dctx)
             f32x4 cxv = zero4();
             const float* cxp = a.ctx + ((int64_t)t * B + qb) * Cw + v_off + 4 * tq;
             const bool cx_on = v_need && 4 * tq < v_D;
-            if (cx_on && wave != 0) cxv = *reinterpret_cast<const f32x4*>(cxp);      // (wave 0 polls: nothing in flight there)
+            const bool cx_now = wave != 0 || !pend || !__builtin_amdgcn_readfirstlane((int)bar.leader);      // (as the cells' early loads)
+            if (cx_on && cx_now) cxv = *reinterpret_cast<const f32x4*>(cxp);
             if (pend) { ok = gb::wait(bar); pend = false; }
             if (!ok) break;
             MMQG_GSTAMP(12)
-            if (cx_on && wave == 0) cxv = *reinterpret_cast<const f32x4*>(cxp);
+            if (cx_on && !cx_now) cxv = *reinterpret_cast<const f32x4*>(cxp);
             // dctx(t)[qb][modality columns] = sum over the slices' row-major partial blocks; 128 threads per modality
             float* dotp = reinterpret_cast<float*>(frag + 3 * 128);       // [8] per-wave parts of ctx . dctx
             if (v_need) {
@@ -524,37 +607,11 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             __syncthreads();
             MMQG_GSTAMP(13)
             if (it_mod >= 0) {
-                f32x4 dv[kK];
-#pragma unroll
-                for (int k = 0; k < kK; ++k) {
-                    const int cq = cl + 16 * k;
-                    dv[k] = cq < Dq ? frag[it_mod * 128 + cq] : zero4();
-                }
                 const float dot = dotp[2 * it_mod] + dotp[2 * it_mod + 1];
                 float* dsr = a.dscores + ((int64_t)t * B + qb) * a.ldD + seg_off;
-                for (int r = it_r0; r < it_r1; r += 4) {
-                    float p = 0.f;
-#pragma unroll
-                    for (int k = 0; k < kK; ++k) p += dot4(cur[k], dv[k]);
-                    const float aw = a_cur;
-#pragma unroll
-                    for (int k = 0; k < kK; ++k) cur[k] = nxt[k];
-                    a_cur = a_nxt;
-                    if (r + 8 < it_r1) {
-#pragma unroll
-                        for (int k = 0; k < kK; ++k) {
-                            const int cq = cl + 16 * k;
-                            nxt[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, cq < Dq ? (min(r + 8 + rg, last) * D + 4 * cq) * 4 : oob, 0, 0));
-                        }
-                        a_nxt = (cl == 0 && r + 8 + rg < it_r1) ? arow[r + 8 + rg] : 0.f;
-                    }
-                    p = sum16(p);
-                    const int ri = r + rg;
-                    if (cl == 0 && ri < it_r1) {
-                        const float da = ri < n_stream ? p : 0.f;
-                        __hip_atomic_store(dsr + ri, aw * (da - dot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through
-                    }
-                }
+                const f32x4* vec = frag + it_mod * 128;
+                if (lg == 3) att_stream<3>(cur, nxt, a_cur, a_nxt, rv, arow, dsr, vec, dot, it_r0, it_r1, n_stream, rg, cl, last, D, Dq, oob);
+                else att_stream<1>(cur, nxt, a_cur, a_nxt, rv, arow, dsr, vec, dot, it_r0, it_r1, n_stream, rg, cl, last, D, Dq, oob);
             }
             MMQG_GSTAMP(14)
             gb::arrive(bar);
@@ -610,6 +667,10 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
                 }
             }
         }
+    }
+    if (TRACE) {
+        __syncthreads();
+        for (int i = tid; i < a.T * kTraceSlots; i += kThreads) a.trace[(size_t)blockIdx.x * a.T * kTraceSlots + i] = stamps[i];
     }
     if (!ok) {
         gb::report_failure(a.sticky_fail, a.host_fail);
@@ -779,6 +840,7 @@ int decoder_seq_bwd_persistent(const mmqg_decoder_seq& d, const mmqg_decoder_seq
     a.tpcL2 = p.tpcL2; a.tpcL1 = p.tpcL1; a.tpcL0 = p.tpcL0; a.tpcA = p.tpcA;
     a.nchS = p.nchS; a.NKR = p.NKR; a.cpk = p.cpk;
     a.cpq = p.cpq; a.n_t = p.n_t; a.n_v = p.n_v; a.n_a = p.n_a;
+    { static const int dbg = [] { const char* e = getenv("MMQG_PDB_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     a.v = v;
     a.w_ihT1 = d.w_ihT[1]; a.w_ihT2 = d.w_ihT[2];
     a.w_hhT0 = d.w_hhT[0]; a.w_hhT1 = d.w_hhT[1]; a.w_hhT2 = d.w_hhT[2];
@@ -798,8 +860,9 @@ int decoder_seq_bwd_persistent(const mmqg_decoder_seq& d, const mmqg_decoder_seq
     a.expect_wg = (unsigned)(G + persist_test_extra_wg());
     a.max_spins = persist_test_max_spins() ? persist_test_max_spins() : gb::kDefaultSpins;
     a.trace = nullptr;
-    if (g_gtrace_buf && (int64_t)G * T * kTraceSlots <= g_gtrace_words) a.trace = g_gtrace_buf;
-    hipLaunchKernelGGL(fns[ki][a.trace ? 1 : 0], dim3(G), dim3(kThreads), (size_t)p.lds_bytes, s, a);
+    const int trace_lds = T * kTraceSlots * 4;
+    if (g_gtrace_buf && (int64_t)G * T * kTraceSlots <= g_gtrace_words && p.lds_bytes + trace_lds <= kLdsBudget) a.trace = g_gtrace_buf;
+    hipLaunchKernelGGL(fns[ki][a.trace ? 1 : 0], dim3(G), dim3(kThreads), (size_t)(p.lds_bytes + (a.trace ? trace_lds : 0)), s, a);
     g_dec_bwd_launches += 1;
     persist_end(s);
     return check_launch("decoder_persist_bwd");

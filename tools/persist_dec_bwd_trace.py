@@ -38,12 +38,23 @@ for rep in range(3):
     e1.record()
     check(lib.mmqg_decoder_persist_bwd_set_trace(None, 0))
     torch.cuda.synchronize()
+# the unstamped kernel, timed by HIP events (the loop + the two value-gradient kernels behind it)
+torch.cuda.synchronize()
+e0.record()
+for rep in range(10):
+    check(lib.mmqg_decoder_seq_bwd(C.byref(tr.d_dec), C.byref(tr.g_dec), ops._stream()))
+e1.record()
+torch.cuda.synchronize()
+plain_us = e0.elapsed_time(e1) * 100.0
 tr.g_dec.phase = 0
-assert lib.mmqg_decoder_persist_bwd_launch_count() == n0 + 3, "the persistent decoder backward loop did not take this shape"
-t = buf.view(G, T, NSLOT).cpu().double() * 0.01          # us; token index = t (the loop runs T-1 .. 0)
+assert lib.mmqg_decoder_persist_bwd_launch_count() == n0 + 13, "the persistent decoder backward loop did not take this shape"
+raw = buf.view(G, T, NSLOT).cpu()
+assert int((raw[:, :, 0] != 0).sum()) == G * T, "the stamped instantiation did not run (no room for the stamps in LDS?)"
+raw = (raw - raw[:, T - 1:T, 0:1].min()) % (1 << 32)      # low 32 bits of the 100 MHz counter, relative to the first start
+t = raw.double() * 0.01                                   # us; token index = t (the loop runs T-1 .. 0)
 t = t.flip(1)                                             # in execution order
-print(f"decoder backward time loop, {T} tokens, {G} workgroups; all times in us; phase-1 call (loop + value gradients) "
-      f"{e0.elapsed_time(e1) * 1e3:.1f}")
+print(f"decoder backward time loop, {T} tokens, {G} workgroups; all times in us; phase-1 call (loop + value gradients), unstamped kernel, "
+      f"HIP events over 10 calls: {plain_us:.1f} per call")
 per = t[:, 1:, 0].min(0).values - t[:, :-1, 0].min(0).values
 print(f"whole loop (first start -> last dS stored): {float(t[:, -1, 14].max() - t[:, 0, 0].min()):.1f}")
 print(f"token period: mean {float(per.mean()):.2f}  (tokens 2..{T - 2}: {float(per[2:-2].mean()):.2f})")
