@@ -61,10 +61,13 @@ struct X3Problem {
     float4* stats;                   // ping-pong kernel, STATS variant: [M][tiles_n] {max, sum exp(x - max), argmax bits, 0}
     float* colsum; float* colsum2;   // ping-pong kernel, m-major A: out[m] += sum over k of A[k][m] (bias gradients: the
                                      // column sums of the gate gradients ride in the weight-gradient product's staging pass)
+    int q0, qpt;                     // balanced launches: first k-quad (4 chunks = 128 k) of this problem in the launch's
+                                     // list of (tile, k-quad) units, quads per tile
 };
 
 struct X3Batch {
     int n;
+    int total_q;                     // balanced launches: k-quads of all tiles of all problems
     X3Problem p[kMaxProblems];
 };
 
@@ -267,24 +270,63 @@ constexpr int kPLds = 2 * kPBuf;                   // 147,456
 // ds_write_b128 (8-lane groups = 4 rows x 2 halves, or 8 consecutive rows: same-parity rows get distinct f)
 __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ (((row >> 2) ^ (row >> 1)) & 3)) << 4); }
 
-template <bool AK, bool BKM, bool STATS>
+// BAL ("balanced", accumulating products only: C += A B): the (tile, k-quad) units of ALL tiles of all problems — a
+// k-quad = 4 chunks = 128 k — are dealt out evenly over the CUs in tile-major order; a CU's share is cut at tile
+// boundaries into at most kBalSegs segments (the tail of a tile, whole tiles, the head of the next), each segment is ONE
+// workgroup (blockIdx = segment * shares + share; shares with fewer segments leave empty workgroups that exit at once), and
+// every segment adds its partial tile with f32 atomics.  Tiles x chunks need not be a multiple of anything: the decoder's
+// weight-gradient group (270 tiles of 40 chunks: two rounds of one tile per CU, the second 5% full) becomes 10-11 quads
+// per CU instead of 20.  (The segments of a share as a loop around the pipeline inside one workgroup cost 230 spilled
+// registers: hipcc keeps the per-thread roles of both groups alive across the back edge.)
+constexpr int kBalSegs = 4;
+template <bool AK, bool BKM, bool STATS, bool BAL = false>
 __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, w4 = wave & 3, t = tid & 255;
-    int pi = 0;
+    int pi = 0, tile = 0, c0 = 0, c1 = 0;
+    bool lead = true;
+    if (BAL) {
+        // (segment-major: workgroups go to the XCDs round-robin by index — share-major, the first segments of all shares, the
+        // only ones most shares have, would all land on two of the eight XCDs)
+        const int shares = gridDim.x / kBalSegs, seg = blockIdx.x / shares, share = blockIdx.x - seg * shares;
+        int q_cur = (int)((int64_t)share * b.total_q / shares);
+        const int q_end = (int)((int64_t)(share + 1) * b.total_q / shares);
+        for (int sidx = 0; ; ++sidx) {
+            if (q_cur >= q_end) return;                       // this share has fewer segments
+            pi = 0;
 #pragma unroll
-    for (int i = 1; i < kMaxProblems; ++i)
-        if (i < b.n && (int)blockIdx.x >= b.p[i].wg0) pi = i;
+            for (int i = 1; i < kMaxProblems; ++i)
+                if (i < b.n && q_cur >= b.p[i].q0) pi = i;
+            const int qpt = b.p[pi].qpt, lt = q_cur - b.p[pi].q0;
+            tile = lt / qpt;
+            const int qq = lt - tile * qpt, take = min(qpt - qq, q_end - q_cur);
+            if (sidx == seg) {
+                const int nchp = (b.p[pi].K + kBK - 1) / kBK;
+                c0 = 4 * qq; c1 = min(nchp, 4 * (qq + take));
+                lead = qq == 0;
+                break;
+            }
+            q_cur += take;
+        }
+    } else {
+#pragma unroll
+        for (int i = 1; i < kMaxProblems; ++i)
+            if (i < b.n && (int)blockIdx.x >= b.p[i].wg0) pi = i;
+    }
     const X3Problem& p = b.p[pi];
-    const int local = blockIdx.x - p.wg0;
-    const int ks = local % p.split_k, tile = local / p.split_k;
+    const int nch = (p.K + kBK - 1) / kBK;
+    if (!BAL) {
+        const int local = blockIdx.x - p.wg0;
+        const int ks = local % p.split_k;
+        tile = local / p.split_k;
+        const int per = (nch + p.split_k - 1) / p.split_k;
+        c0 = ks * per; c1 = min(nch, c0 + per);
+        lead = ks == 0;
+    }
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int m0 = tm * kPM, n0 = tn * kPN;
-    const int nch = (p.K + kBK - 1) / kBK;
-    const int per = (nch + p.split_k - 1) / p.split_k;
-    const int c0 = ks * per, c1 = min(nch, c0 + per);
     const int n_ch = c1 - c0;
 
     f32x16 acc[2][2];
@@ -512,7 +554,6 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
         }
         return;
     }
-    const bool lead = ks == 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wc * 64 + j * 32 + (lane & 31);
@@ -527,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
                 if (m >= p.M) continue;
                 float* dst = p.C + (int64_t)m * p.ldc + n;
                 const float v = acc[i][j][e] + bsum;
-                if (p.split_k > 1) atomicAdd(dst, v);
+                if (BAL || p.split_k > 1) atomicAdd(dst, v);
                 else *dst = p.beta ? *dst + v : v;
             }
     }
@@ -551,17 +592,17 @@ int x3_cus() {
 
 bool aligned16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-template <bool AK, bool BKM, bool STATS = false>
+template <bool AK, bool BKM, bool STATS = false, bool BAL = false>
 int launch_pp(const X3Batch& b, int wgs, hipStream_t s) {
     static int attr = 0;
     if (attr == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3pp_kernel<AK, BKM, STATS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3pp_kernel<AK, BKM, STATS, BAL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kPLds);
         if (e != hipSuccess) (void)hipGetLastError();
         attr = e == hipSuccess ? 1 : -1;
     }
     if (attr < 0) return 1;
-    hipLaunchKernelGGL((gemm_x3pp_kernel<AK, BKM, STATS>), dim3(wgs), dim3(512), (size_t)kPLds, s, b);
+    hipLaunchKernelGGL((gemm_x3pp_kernel<AK, BKM, STATS, BAL>), dim3(wgs), dim3(512), (size_t)kPLds, s, b);
     return check_launch("gemm_x3pp");
 }
 
@@ -632,6 +673,42 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
         for (int i = 0; i < ng; ++i) {
             const GemmProblem& q = probs[g0 + i];
             tiles_total += (int64_t)ceil_div(q.M, tile_m) * ceil_div(q.N, tile_n);
+        }
+        // Accumulating weight-gradient groups (both operands m/n-major, every C += ...): one workgroup per CU and the k-quads
+        // of all tiles dealt out evenly (BAL above) — no tile-count quantisation, no read-modify-write epilogue.
+        // MMQG_X3_BAL=0: the one-tile-per-workgroup launches below (A/B).
+        static const bool bal_on = [] { const char* e = getenv("MMQG_X3_BAL"); return !e || atoi(e) != 0; }();
+        bool all_beta = pp && bal_on && a_layout == MMQG_MN_MAJOR && b_layout == MMQG_MN_MAJOR;
+        for (int i = 0; i < ng && all_beta; ++i) all_beta = probs[g0 + i].beta != 0;
+        if (all_beta) {
+            int q = 0;
+            for (int i = 0; i < ng; ++i) {
+                const GemmProblem& gp = probs[g0 + i];
+                X3Problem& p = b.p[i];
+                p.M = gp.M; p.N = gp.N; p.K = gp.K;
+                p.A = gp.A; p.lda = gp.lda; p.B = gp.B; p.ldb = gp.ldb; p.C = gp.C; p.ldc = gp.ldc;
+                p.bias = bias ? bias[g0 + i] : nullptr; p.bias2 = bias2 ? bias2[g0 + i] : nullptr;       // (added by a tile's first segment)
+                p.colsum = colsum ? colsum[g0 + i] : nullptr; p.colsum2 = (colsum && colsum2) ? colsum2[g0 + i] : nullptr;
+                p.beta = 1; p.split_k = 1; p.wg0 = 0;
+                p.tiles_n = ceil_div(gp.N, tile_n);
+                p.qpt = ceil_div(ceil_div(gp.K, kBK), 4);
+                p.q0 = q;
+                q += ceil_div(gp.M, tile_m) * p.tiles_n * p.qpt;
+            }
+            b.total_q = q;
+            const int shares = std::min(x3_cus(), q);
+            // a share of R quads crosses at most 2 + R / (quads per tile) tile boundaries
+            int min_qpt = 1 << 30;
+            for (int i = 0; i < ng; ++i) min_qpt = std::min(min_qpt, b.p[i].qpt);
+            const bool fits = ceil_div(q, shares) / min_qpt + 2 <= kBalSegs;
+            const int rc = fits ? launch_pp<false, false, false, true>(b, kBalSegs * shares, s) : 1;
+            if (fits) {
+                if (rc > 0 && g0 > 0) { set_error("gemm_x3: launch refused after part of the group ran"); return -1; }
+                if (rc != 0) return rc;
+                continue;
+            }
+            b = X3Batch{};                     // (a share would span too many tiles: one tile per workgroup below)
+            b.n = ng;
         }
         // k slices: fill the chip's workgroup slots once, keep >= 8 chunks per slice
         const int slots = (pp ? 1 : 2) * x3_cus();
