@@ -68,6 +68,7 @@ struct X3Problem {
 struct X3Batch {
     int n;
     int total_q;                     // balanced launches: k-quads of all tiles of all problems
+    int dword_epilogue;              // MMQG_X3_DWORD_EPILOGUE=1 (A/B): the lane-per-column epilogue for every product but the projection
     X3Problem p[kMaxProblems];
 };
 
@@ -496,10 +497,14 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
         }
     }
 
-    if (STATS) {
-        // Projection with loss statistics (decoder.py:106 + train.py:174; one k slice, no beta): the tile goes through
-        // the LDS (free now) and comes back row by row: bias, the row's max / first argmax / sum-exp over the tile's
-        // 128 columns, and fully coalesced 16-byte stores.
+    // Epilogue through the LDS (free now): the tile comes back row by row, a half-wave per row, 16 bytes per lane — 512
+    // contiguous bytes per row and instruction.  The projection (STATS: decoder.py:106 + train.py:174; one k slice, no beta)
+    // also takes bias, the row's max / first argmax / sum-exp over the tile's 128 columns there.  Every other product takes
+    // its C += / = / atomic-add in that shape too when C allows 16-byte accesses: with a lane holding one column and 16
+    // rows the accumulating epilogue was 64 dependent dword load-add-store rounds (33 us of a 256 x 128 tile's time,
+    // against 14 for plain dword stores: tools/x3_fixed_cost.py).
+    const bool c_vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && !b.dword_epilogue;
+    if (STATS || c_vec) {
         constexpr int kTS = 132;                             // floats per staged row (128 + 4: ds_read_b128-aligned)
         float* T = reinterpret_cast<float*>(smem);
         __syncthreads();                                     // every wave is done reading the operand buffers
@@ -518,15 +523,43 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
         const int l32 = tid & 31, hw = tid >> 5;
         const int n = n0 + 4 * l32;
         f32x4 bias4{0.f, 0.f, 0.f, 0.f};
+        if (STATS || lead) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) bias4[e] = (p.bias ? p.bias[n + e] : 0.f) + (p.bias2 ? p.bias2[n + e] : 0.f);
-        const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && n + 3 < p.N;
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) bias4[e] = (p.bias ? p.bias[n + e] : 0.f) + (p.bias2 ? p.bias2[n + e] : 0.f);
+        }
+        const bool vec_ok = c_vec && n + 3 < p.N;
+        const bool atomic = !STATS && (BAL || p.split_k > 1), accum = !STATS && p.beta != 0;
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int row = hw + 16 * it;
             const int m = m0 + row;
             f32x4 v = *reinterpret_cast<const f32x4*>(T + row * kTS + 4 * l32) + bias4;
+            if (!STATS) {
+                if (m >= p.M) continue;
+                float* crow = p.C + (int64_t)m * p.ldc;
+                if (atomic) {
+                    // (f32 atomics run at full rate for 128 contiguous bytes per half-wave, at a quarter of it for 4 of
+                    // every 16 bytes: here lane l takes columns l, l + 32, l + 64, l + 96 of the row)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int nn = n0 + 32 * e + l32;
+                        if (nn < p.N) {
+                            float x = T[row * kTS + 32 * e + l32];
+                            if (lead) x += (p.bias ? p.bias[nn] : 0.f) + (p.bias2 ? p.bias2[nn] : 0.f);
+                            atomicAdd(crow + nn, x);
+                        }
+                    }
+                } else if (vec_ok) {
+                    if (accum) v += *reinterpret_cast<const f32x4*>(crow + n);
+                    *reinterpret_cast<f32x4*>(crow + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) crow[n + e] = accum ? crow[n + e] + v[e] : v[e];
+                }
+                continue;
+            }
             float best = -INFINITY;
             int bi = 0x7fffffff;
 #pragma unroll
@@ -667,8 +700,10 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
     }
     for (int g0 = 0; g0 < n; g0 += kMaxProblems) {
         const int ng = std::min(kMaxProblems, n - g0);
+        static const int dword_epi = [] { const char* e = getenv("MMQG_X3_DWORD_EPILOGUE"); return e && atoi(e) != 0 ? 1 : 0; }();
         X3Batch b{};
         b.n = ng;
+        b.dword_epilogue = dword_epi;
         int64_t tiles_total = 0;
         for (int i = 0; i < ng; ++i) {
             const GemmProblem& q = probs[g0 + i];
@@ -676,8 +711,10 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
         }
         // Accumulating weight-gradient groups (both operands m/n-major, every C += ...): one workgroup per CU and the k-quads
         // of all tiles dealt out evenly (BAL above) — no tile-count quantisation, no read-modify-write epilogue.
-        // MMQG_X3_BAL=0: the one-tile-per-workgroup launches below (A/B).
-        static const bool bal_on = [] { const char* e = getenv("MMQG_X3_BAL"); return !e || atoi(e) != 0; }();
+        // OPT-IN (MMQG_X3_BAL=1).  Measured (round 4): alone, a half-filled launch gains (2048 x 2048 x 2048, 128 tiles: 176 -> 137 us),
+        // but in the step every weight-gradient group loses (text encoder 728 -> 820 us, frame encoder 140 -> 171 us per phase):
+        // two atomic epilogues per CU instead of one 16-byte read-modify-write, and workgroups of unequal length dealt out greedily.
+        static const bool bal_on = [] { const char* e = getenv("MMQG_X3_BAL"); return e && atoi(e) != 0; }();
         bool all_beta = pp && bal_on && a_layout == MMQG_MN_MAJOR && b_layout == MMQG_MN_MAJOR;
         for (int i = 0; i < ng && all_beta; ++i) all_beta = probs[g0 + i].beta != 0;
         if (all_beta) {
@@ -709,6 +746,7 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
             }
             b = X3Batch{};                     // (a share would span too many tiles: one tile per workgroup below)
             b.n = ng;
+            b.dword_epilogue = dword_epi;
         }
         // k slices: fill the chip's workgroup slots once, keep >= 8 chunks per slice
         const int slots = (pp ? 1 : 2) * x3_cus();
