@@ -306,7 +306,10 @@ def loop_rooflines(tr, w):
             ("decoder_fwd", dec_fwd, Td, "token", dec_flop, dec_bytes,
              "persistent: 5 device-wide barriers per token, recurrent weights resident in LDS" if tr.d_dec.persist_ws
              else "5 dependent launches per token"),
-            ("decoder_bwd", dec_bwd, Td, "token", 2 * dec_flop, dec_bytes + B * vals, "5 dependent launches per token"),
+            ("decoder_bwd", dec_bwd, Td, "token", 2 * dec_flop, dec_bytes + B * vals,
+             "persistent: 5 device-wide barriers per token (score-gradient product, three cell stages whose k-slices the "
+             "consumer sums, attention backward), recurrent weights resident in LDS; includes the two value-gradient kernels "
+             "behind the loop" if tr.g_dec.persist_ws else "5 dependent launches per token"),
             ("text_encoder_fwd", text_fwd, Tc + L - 1, "diagonal", text_flop, 4 * B * 2 * H * L,
              "persistent: 1 device-wide barrier per diagonal, weights resident in LDS"),
             ("text_encoder_bwd", text_bwd, Tc + L - 1, "diagonal", text_flop, 4 * B * 8 * H * L,
@@ -319,7 +322,8 @@ def loop_rooflines(tr, w):
                      "distinct_operand_bytes_per_" + unit: int(nbytes), "achieved_gbs": round(nbytes / per / 1e9, 1),
                      "frac_of_hbm_peak": round(nbytes / per / 1e9 / HBM_PEAK_GBS, 4), "bound": "latency: " + stages}
     out["persistent_launches"] = {"forward": int(lib.mmqg_persist_launch_count()), "backward": int(lib.mmqg_persist_bwd_launch_count()),
-                                  "decoder_forward": int(lib.mmqg_decoder_persist_launch_count())}
+                                  "decoder_forward": int(lib.mmqg_decoder_persist_launch_count()),
+                                  "decoder_backward": int(lib.mmqg_decoder_persist_bwd_launch_count())}
     return out
 
 

@@ -508,6 +508,12 @@ typedef struct {
     int32_t* ctx_len_out; int32_t* tgt_len_out; int32_t* n_frames_out;
 } mmqg_batch_pack;
 int mmqg_pack_batch(const mmqg_batch_pack* a, mmqg_stream stream);
+/* Host batches (train.py:144-162: the DataLoader hands every batch over in host memory).  src: PINNED host memory that is
+ * mapped into the device's address space (hipHostMalloc, torch pin_memory()); the kernel reads it itself over PCIe with
+ * 16-byte loads and writes dst (device).  At most 8 segments per call, ONE launch, no copy-engine call: it can sit on a
+ * second stream beside the previous step's graph replay.  The caller keeps src unchanged until the launch has run. */
+typedef struct { void* dst; const void* src; int64_t bytes; } mmqg_copy_seg;
+int mmqg_fetch_mapped(const mmqg_copy_seg* segs, int n, mmqg_stream stream);
 
 #ifdef __cplusplus
 }

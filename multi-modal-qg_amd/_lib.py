@@ -99,6 +99,10 @@ class DecoderSeqGrad(C.Structure):
                 ("persist_ws", c_f), ("persist_ws_bytes", c_i64)]
 
 
+class CopySeg(C.Structure):
+    _fields_ = [("dst", c_f), ("src", c_f), ("bytes", c_i64)]
+
+
 class TransposeJob(C.Structure):
     _fields_ = [("src", c_f), ("ld_src", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("dst", c_f),
                 ("ld_dst", C.c_int32)]
@@ -149,6 +153,7 @@ SIGNATURES = {
                       c_i, c_f],
     "mmqg_gemm_f32_grouped": [c_i, c_i, C.POINTER(GemmProblem), c_i, c_f],
     "mmqg_pack_batch": [C.POINTER(BatchPack), c_f],
+    "mmqg_fetch_mapped": [C.POINTER(CopySeg), c_i, c_f],
     "mmqg_embedding_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mmqg_embedding_bwd": [c_f, c_i, c_f, c_f, c_i, c_i, c_i, c_f],
     "mmqg_attn_softmax_context_fwd": [C.POINTER(AttnValues), c_f, c_i, c_f, c_i, c_f, c_i, c_f],

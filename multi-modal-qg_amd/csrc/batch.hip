@@ -4,6 +4,8 @@
 // the teacher-forcing decoder inputs (<start>, then target[t-1]: train.py:168,175), the per-row loss weights
 // (t < target_len) / B, and the three length vectors, clamped to the static extents [0, Tc] / [0, Td] / [0, Tf]
 // (the BatchNorm frame counts and the masks downstream trust them).  Replaces ~25 small framework kernels per step.
+#include <algorithm>
+
 #include "mmqg_common.h"
 #include "mmqg_kernels.h"
 
@@ -47,9 +49,61 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(mmqg_batch_pack a, int6
     }
 }
 
+// A batch that starts in HOST memory (what the reference's DataLoader hands over, train.py:144-162): the kernel reads
+// the pinned, device-mapped host buffers itself — 16 bytes per lane over PCIe — into device staging buffers.  No
+// copy-engine call sits between two replays of the step graph (an asynchronous hipMemcpy there cost ~18 ms per step on
+// this stack), the launch can run on a second stream beside the previous step, and it is one
+// kernel for all seven tensors of a batch.  Few workgroups: the transfer is PCIe-bound, not CU-bound.
+constexpr int kFetchSegs = 8;
+struct FetchBatch { void* dst[kFetchSegs]; const void* src[kFetchSegs]; int64_t bytes[kFetchSegs]; int n; };
+
+__global__ __launch_bounds__(256) void fetch_mapped_kernel(FetchBatch f) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+#pragma unroll
+    for (int s = 0; s < kFetchSegs; ++s) {
+        if (s >= f.n) break;
+        const int64_t nb = f.bytes[s];
+        const bool vec = ((reinterpret_cast<uintptr_t>(f.dst[s]) | reinterpret_cast<uintptr_t>(f.src[s])) & 15) == 0;
+        if (vec) {
+            const uint4* src = reinterpret_cast<const uint4*>(f.src[s]);
+            uint4* dst = reinterpret_cast<uint4*>(f.dst[s]);
+            const int64_t n16 = nb >> 4;
+            for (int64_t i = tid; i < n16; i += 2 * stride) {           // two loads in flight per lane
+                const int64_t j = i + stride;
+                const uint4 a = src[i];
+                uint4 b = a;
+                if (j < n16) b = src[j];
+                dst[i] = a;
+                if (j < n16) dst[j] = b;
+            }
+            for (int64_t i = (n16 << 4) + tid; i < nb; i += stride)
+                reinterpret_cast<unsigned char*>(f.dst[s])[i] = reinterpret_cast<const unsigned char*>(f.src[s])[i];
+        } else {
+            for (int64_t i = tid; i < nb; i += stride)
+                reinterpret_cast<unsigned char*>(f.dst[s])[i] = reinterpret_cast<const unsigned char*>(f.src[s])[i];
+        }
+    }
+}
+
 }  // namespace
 
 namespace mmqg {
+
+int fetch_mapped(const mmqg_copy_seg* segs, int n, hipStream_t s) {
+    MMQG_REQUIRE(n >= 0 && n <= kFetchSegs && (n == 0 || segs), "fetch_mapped: between 0 and %d segments", kFetchSegs);
+    FetchBatch f{};
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        MMQG_REQUIRE(segs[i].bytes >= 0 && (segs[i].bytes == 0 || (segs[i].dst && segs[i].src)), "fetch_mapped: bad segment %d", i);
+        f.dst[i] = segs[i].dst; f.src[i] = segs[i].src; f.bytes[i] = segs[i].bytes;
+        total += segs[i].bytes;
+    }
+    f.n = n;
+    if (total == 0) return 0;
+    const int blocks = (int)std::min<int64_t>(64, std::max<int64_t>(1, total / (256 * 32)));
+    hipLaunchKernelGGL(fetch_mapped_kernel, dim3(blocks), dim3(256), 0, s, f);
+    return check_launch("fetch_mapped");
+}
 
 int pack_batch(const mmqg_batch_pack& a, hipStream_t s) {
     MMQG_REQUIRE(a.B >= 0 && a.Tf >= 0 && a.Tc >= 0 && a.Td >= 0 && a.Da >= 0 && a.audio_rows >= 0 && a.frame_inner >= 0,

@@ -56,6 +56,7 @@ int mmqg_pack_batch(const mmqg_batch_pack* a, mmqg_stream stream) {
     MMQG_REQUIRE(a, "mmqg_pack_batch: null descriptor");
     return pack_batch(*a, S(stream));
 }
+int mmqg_fetch_mapped(const mmqg_copy_seg* segs, int n, mmqg_stream stream) { return fetch_mapped(segs, n, S(stream)); }
 int mmqg_embedding_fwd(const float* table, const int64_t* ids, float* out, int n, int V, int E, int ld_out,
                        mmqg_stream stream) {
     return embedding_fwd(table, ids, out, n, V, E, ld_out, S(stream));

@@ -195,6 +195,7 @@ int frame_cnn_bwd(const mmqg_frame_cnn& d, const mmqg_frame_cnn_grad& g, hipStre
 
 // ---- batch.hip ----
 int pack_batch(const mmqg_batch_pack& a, hipStream_t s);
+int fetch_mapped(const mmqg_copy_seg* segs, int n, hipStream_t s);
 
 // ---- adam.hip -------------------------------------------------------------------------
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps,

@@ -292,6 +292,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     f32x4* frag = lds + wbs + a.cpk * 64;
     unsigned* stamps = reinterpret_cast<unsigned*>(frag + kFragF4);      // [T][kTraceSlots], stamped instantiation only
     if (TRACE) for (int i = tid; i < a.T * kTraceSlots; i += kThreads) stamps[i] = 0u;
+    const unsigned t_entry = TRACE ? (unsigned)wall_clock64() : 0u;      // (slot 15 of the first token: kernel entry, before the weights are read)
 
     // my tiles of a layer: late tiles [cg * tpcL, ...) of nlate, ahead tiles [cg * tpcA, ...) of H/16
     const int nL2 = cellwg ? max(0, min(tpcL2, nlate21 - cg * tpcL2)) : 0;
@@ -301,20 +302,42 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
 
     // ---- weights -> LDS in fragment order: tile, chunk c, lane (i = lane & 15: output column of the tile, kq = lane >> 4):
     // the four k = 16 c + 4 kq + {0..3} of the slice, i.e. gate c >> 1, units 32 sl + 16 (c & 1) + 4 kq + {0..3}: one
-    // 16-byte load from the k-major copy WT[n][gate * H + unit]
+    // 16-byte load from the k-major copy WT[n][gate * H + unit].  The items of all six blocks form ONE list that is read
+    // eight 16-byte loads per thread at a time, in SOURCE order — 8 consecutive lanes cover the 128 contiguous bytes of a
+    // (column, gate) pair, i.e. whole cache lines — and scattered into the LDS (120 KB per workgroup, 30 MB per launch: a
+    // loop of one load + one store per thread and matrix took ~60 us of the launch).
     {
         const float* srcs[6] = {a.w_ihT2, a.w_hhT2, a.w_ihT1, a.w_hhT1, a.w_ih0cT, a.w_hhT0};
         const int wbase[6] = {wb2, wb2 + tpcL2 * 512, wb1, wb1 + tpcL1 * 512, wb0, wb0 + tpcL0 * 512};
         const int first[6] = {cg * tpcL2, cg * tpcA, cg * tpcL1, cg * tpcA, cg * tpcL0, cg * tpcA};
         const int count[6] = {nL2, nA, nL1, nA, nL0, nA};
+        int start[7];
+        start[0] = 0;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            for (int idx = tid; idx < count[m] * 512; idx += kThreads) {
-                const int tl = idx >> 9, c = (idx >> 6) & 7, l = idx & 63, i = l & 15, kq = l >> 4;
-                const int n = 16 * (first[m] + tl) + i;
-                const int k = (c >> 1) * H + kU * sl + 16 * (c & 1) + 4 * kq;
-                lds[wbase[m] + idx] = *reinterpret_cast<const f32x4*>(srcs[m] + (int64_t)n * 4 * H + k);
+        for (int m = 0; m < 6; ++m) start[m + 1] = start[m] + count[m] * 512;
+        constexpr int kUn = 8;
+        for (int base = 0; base < start[6]; base += kUn * kThreads) {
+            f32x4 v[kUn];
+            int dst[kUn];
+#pragma unroll
+            for (int u = 0; u < kUn; ++u) {
+                const int it = base + u * kThreads + tid;
+                int m = 0;
+#pragma unroll
+                for (int mm = 1; mm < 6; ++mm) m = it >= start[mm] ? mm : m;
+                const float* src = m == 0 ? srcs[0] : (m == 1 ? srcs[1] : (m == 2 ? srcs[2] : (m == 3 ? srcs[3] : (m == 4 ? srcs[4] : srcs[5]))));
+                const int st = m == 0 ? start[0] : (m == 1 ? start[1] : (m == 2 ? start[2] : (m == 3 ? start[3] : (m == 4 ? start[4] : start[5]))));
+                const int fi = m == 0 ? first[0] : (m == 1 ? first[1] : (m == 2 ? first[2] : (m == 3 ? first[3] : (m == 4 ? first[4] : first[5]))));
+                const int wbm = m == 0 ? wbase[0] : (m == 1 ? wbase[1] : (m == 2 ? wbase[2] : (m == 3 ? wbase[3] : (m == 4 ? wbase[4] : wbase[5]))));
+                const int loc = it - st, tl = loc >> 9, jj = loc & 511;
+                const int u4 = jj & 7, gate = (jj >> 3) & 3, ni = jj >> 5;
+                const bool on = it < start[6];
+                dst[u] = on ? wbm + tl * 512 + (2 * gate + (u4 >> 2)) * 64 + (u4 & 3) * 16 + ni : -1;
+                v[u] = on ? *reinterpret_cast<const f32x4*>(src + (int64_t)(16 * (fi + tl) + ni) * 4 * H + gate * H + kU * sl + 4 * u4) : zero4();
             }
+#pragma unroll
+            for (int u = 0; u < kUn; ++u)
+                if (dst[u] >= 0) lds[dst[u]] = v[u];
         }
     }
     // score-gradient product: workgroup (sl, cg) owns column tile 2 sl + (cg & 1) and k-range cg >> 1
@@ -392,6 +415,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     const bool rvalid = ln < B;                                                       \
     (void)row; (void)rowc; (void)j; (void)q; (void)rvalid;
 
+    if (TRACE && tid == 0) stamps[(T - 1) * kTraceSlots + 15] = t_entry;
     for (int t = T - 1; ok && t >= 0; --t) {
         MMQG_GSTAMP(0)
         const int tok = t * tok_stride, tok1 = (t + 1) * tok_stride;
@@ -668,6 +692,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             }
         }
     }
+    if (TRACE && tid == 0) stamps[15] = (unsigned)wall_clock64();      // (slot 15 of token 0: the initial-state gradients are stored)
     if (TRACE) {
         __syncthreads();
         for (int i = tid; i < a.T * kTraceSlots; i += kThreads) a.trace[(size_t)blockIdx.x * a.T * kTraceSlots + i] = stamps[i];

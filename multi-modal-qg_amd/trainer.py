@@ -41,6 +41,30 @@ def _round4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
+_HIP = None
+
+
+def _registered_host_tensor(shape, dtype):
+    """A host tensor the device can read directly AND the CPU can fill at memcpy speed: ordinary (cached) memory registered
+    with hipHostRegister(portable | mapped) — ordinary cacheable pages, whatever the runtime does with hipHostMalloc memory.
+    Returns (tensor, device address).  The registration lives as long as the process (two small sets per trainer)."""
+    global _HIP
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+        _HIP.hipHostGetDevicePointer.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint]
+    t = torch.empty(tuple(shape), dtype=dtype)
+    nbytes = max(t.numel() * t.element_size(), 1)
+    rc = _HIP.hipHostRegister(C.c_void_p(t.data_ptr()), nbytes, 3)          # hipHostRegisterPortable | hipHostRegisterMapped
+    if rc != 0:
+        raise _lib.BackendError(f"hipHostRegister failed ({rc})")
+    dp = C.c_void_p()
+    rc = _HIP.hipHostGetDevicePointer(C.byref(dp), C.c_void_p(t.data_ptr()), 0)
+    if rc != 0 or not dp.value:
+        raise _lib.BackendError(f"hipHostGetDevicePointer failed ({rc})")
+    return t, dp.value
+
+
 class BatchedTrainer:
     def __init__(self, av_enc_model, text_enc_model, dec_model, *, batch_size: int, n_frames: int, ctx_len: int,
                  tgt_len: int, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, start_id: int = 1,
@@ -458,6 +482,9 @@ class BatchedTrainer:
         ``context`` (B,Tc) ids; ``target`` (B,Td) ids; ``ctx_len``/``tgt_len``/``n_frames`` (B,).
         Raw frames switch the HIP frame CNN on for the following forward / backward."""
         w, B, dev = self.ws, self.B, self.dev
+        staged = None
+        if batch["frames"].device.type == "cpu" and os.environ.get("MMQG_HOST_BATCH", "mapped") != "copy":
+            batch, staged = self._stage_host_batch(batch)
         frames = batch["frames"]
         self._cnn_on = frames.dim() == 5
         if self._cnn_on:
@@ -490,6 +517,8 @@ class BatchedTrainer:
                            row_w=w["row_w"].data_ptr(), ctx_len_out=w["ctx_len"].data_ptr(),
                            tgt_len_out=w["tgt_len"].data_ptr(), n_frames_out=w["n_frames"].data_ptr())
         check(_lib.load().mmqg_pack_batch(C.byref(p), ops._stream()), "pack_batch")
+        if staged is not None:            # the device staging set may be refilled once this launch has read it
+            staged.record(torch.cuda.current_stream())
         # the pack kernel writes audio rows [0, audio.shape[1]); rows a previous, longer batch left behind are
         # padding now (train.py:156 pads with zeros) and the no-op masks attend every row
         rows = audio.shape[1]
@@ -498,6 +527,66 @@ class BatchedTrainer:
         self._audio_rows = rows
         # the gradient of the frame LSTM's input is only needed when a CNN produced that input
         self.g_vid.dx = w["dfeats"].data_ptr() if self._cnn_on else None
+
+    _HOST_KEYS = (("frames", torch.float32), ("audio", torch.float32), ("context", torch.int64), ("target", torch.int64),
+                  ("ctx_len", torch.int32), ("tgt_len", torch.int32), ("n_frames", torch.int32))
+
+    def _stage_host_batch(self, batch: dict):
+        """A batch in HOST memory (what the reference's DataLoader hands over, train.py:144-162) on its way to the device
+        without a copy-engine call between two replays of the step graph: the tensors go into one of two pinned staging
+        sets (tensors that already are pinned are read in place), ONE kernel on a second stream reads them over PCIe
+        (``mmqg_fetch_mapped``) into a device staging set — beside the previous step, which the host is a step ahead of —
+        and the compute stream waits for that kernel only.  Returns (device batch, event to record after the pack
+        launch).  MMQG_HOST_BATCH=copy: blocking ``.to()`` copies (round 3); =async_memcpy: the same staging with
+        ``copy_(non_blocking=True)`` instead of the kernel (diagnostic: the variant that ran at 22 ms per step)."""
+        mode = os.environ.get("MMQG_HOST_BATCH", "mapped")
+        sig = tuple((k, tuple(batch[k].shape)) for k, _ in self._HOST_KEYS)
+        hb = getattr(self, "_hb", None)
+        if hb is None or hb["sig"] != sig:
+            hb = dict(sig=sig, slot=0, stream=torch.cuda.Stream(device=self.dev), sets=[])
+            for _ in range(2):
+                host, hptr = {}, {}
+                for k, dt in self._HOST_KEYS:
+                    host[k], hptr[k] = _registered_host_tensor(batch[k].shape, dt)
+                devs = {k: torch.empty(batch[k].shape, dtype=dt, device=self.dev) for k, dt in self._HOST_KEYS}
+                hb["sets"].append(dict(host=host, hptr=hptr, dev=devs, ready=None, packed=None, keep=None))
+            self._hb = hb
+        hb["slot"] ^= 1
+        st = hb["sets"][hb["slot"]]
+        if st["ready"] is not None:
+            st["ready"].synchronize()          # the launch that read this set's host buffers two batches ago has run
+        src, sptr = {}, {}
+        for k, dt in self._HOST_KEYS:
+            t = batch[k]
+            if t.dtype == dt and t.is_contiguous() and t.is_pinned():
+                src[k], sptr[k] = t, t.data_ptr()        # already pinned (DataLoader(pin_memory=True)): read in place
+            else:
+                h = st["host"][k]
+                if t.dtype == dt and t.is_contiguous():
+                    # one plain memcpy: torch's copy_ fans a 4 MB copy out over every CPU it sees (256 on the GPU box, of
+                    # which the process may use 16) and took 12 ms per batch there — round 3's "18 ms per step"
+                    C.memmove(h.data_ptr(), t.data_ptr(), t.numel() * t.element_size())
+                else:
+                    h.copy_(t)
+                src[k], sptr[k] = h, st["hptr"][k]
+        st["keep"] = src                        # alive until the kernel has read them
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(hb["stream"]):
+            if st["packed"] is not None:
+                hb["stream"].wait_event(st["packed"])        # the pack launch that read this device set two batches ago
+            if mode == "async_memcpy":
+                for k, _ in self._HOST_KEYS:
+                    st["dev"][k].copy_(src[k], non_blocking=True)
+            else:
+                segs = (_lib.CopySeg * len(self._HOST_KEYS))()
+                for sg, (k, _) in zip(segs, self._HOST_KEYS):
+                    sg.dst, sg.src, sg.bytes = st["dev"][k].data_ptr(), sptr[k], src[k].numel() * src[k].element_size()
+                check(_lib.load().mmqg_fetch_mapped(segs, len(segs), ops._stream()), "fetch_mapped")
+            st["ready"] = torch.cuda.Event()
+            st["ready"].record(hb["stream"])
+        cur.wait_event(st["ready"])
+        st["packed"] = torch.cuda.Event()
+        return st["dev"], st["packed"]
 
     # ------------------------------------------------------------------------ one step
     # Two HIP streams: the recurrent time loops are latency-bound chains of small launches, the

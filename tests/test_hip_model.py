@@ -719,6 +719,42 @@ def test_a_failed_persistent_decoder_launch_is_loud(mm):
     assert torch.equal(again, good)
 
 
+@pytest.mark.parametrize("mode", ["mapped", "copy"])
+def test_batches_from_host_memory_give_the_same_steps(mm, mode, monkeypatch):
+    """train.py:144-162 hands every batch over in HOST memory.  The trainer takes it from pageable or pinned host tensors
+    (mapped: one kernel reads the pinned staging set over PCIe on a second stream, two sets taking turns; copy: blocking
+    copies) and must do exactly the steps it does on device-resident batches: four different batches in a row, captured
+    graph: the same losses bit for bit, the same weights to the last bits."""
+    from mmqg_amd.synthetic import Workload, build_models, synthetic_batch
+    monkeypatch.setenv("MMQG_HOST_BATCH", mode)
+    w = Workload("hostbatch", batch=6, n_frames=4, frame_dim=24, audio_dim=16, ctx_len=7, tgt_len=6, vocab=50, emb_dim=12,
+                 hidden=128, layers=3, video_hidden=128, text_max_length=21, av_max_length=9, dropout=0.1)
+    batches = [synthetic_batch(w, seed=40 + i, ragged=True) for i in range(4)]
+    outs = []
+    for kind in ("device", "pageable", "pinned"):
+        vid, text, dec = build_models(w, "cuda", seed=5)
+        tr = _trainer(mm, vid, text, dec, batches[0], seed=9, use_graph=True).train()
+        losses = []
+        for i in range(6):
+            b = batches[i % 4]
+            if kind == "device":
+                b = {k: v.cuda() for k, v in b.items()}
+            elif kind == "pinned":
+                b = {k: v.clone().pin_memory() for k, v in b.items()}
+            losses.append(tr.step(b).clone())
+        torch.cuda.synchronize()
+        tr.check_health(sync=True)
+        outs.append((torch.stack(losses).cpu(), tr.flat_p.clone().cpu()))
+    for kind, (l, p) in zip(("pageable", "pinned"), outs[1:]):
+        # every batch arrived intact: the first four losses are those of four DIFFERENT batches; the first one depends on
+        # nothing else and must be bit-identical.  (Later steps see weights whose gradients were summed with f32 atomics —
+        # two runs on the SAME device batches differ in their last bits, and Adam's first steps turn that into up to lr
+        # per step on elements with tiny gradients: compared with a tolerance.)
+        assert torch.equal(l[0], outs[0][0][0]), f"{mode}: the first loss from {kind} host batches differs"
+        close(l, outs[0][0], tol=1e-5, what=f"{mode}: losses of six steps from {kind} host batches")
+        assert float((p - outs[0][1]).abs().max()) <= 6 * 2.002e-4, f"{mode}: weights after six steps from {kind} host batches"
+
+
 def test_skipping_zero_padded_value_rows_changes_nothing(mm):
     """skip_zero_value_rows: the attention kernels stop at each question's context length / frame count instead of
     streaming the zero padding up to 283 / 101 rows — loss and every gradient must come out the same."""

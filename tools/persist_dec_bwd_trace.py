@@ -50,13 +50,16 @@ tr.g_dec.phase = 0
 assert lib.mmqg_decoder_persist_bwd_launch_count() == n0 + 13, "the persistent decoder backward loop did not take this shape"
 raw = buf.view(G, T, NSLOT).cpu()
 assert int((raw[:, :, 0] != 0).sum()) == G * T, "the stamped instantiation did not run (no room for the stamps in LDS?)"
-raw = (raw - raw[:, T - 1:T, 0:1].min()) % (1 << 32)      # low 32 bits of the 100 MHz counter, relative to the first start
+raw = (raw - raw[:, T - 1:T, 15:16].min()) % (1 << 32)      # low 32 bits of the 100 MHz counter, relative to the first start
 t = raw.double() * 0.01                                   # us; token index = t (the loop runs T-1 .. 0)
 t = t.flip(1)                                             # in execution order
 print(f"decoder backward time loop, {T} tokens, {G} workgroups; all times in us; phase-1 call (loop + value gradients), unstamped kernel, "
       f"HIP events over 10 calls: {plain_us:.1f} per call")
 per = t[:, 1:, 0].min(0).values - t[:, :-1, 0].min(0).values
 print(f"whole loop (first start -> last dS stored): {float(t[:, -1, 14].max() - t[:, 0, 0].min()):.1f}")
+print(f"prologue (kernel entry -> weights in LDS, barrier initialised, first token starts): mean {float((t[:, 0, 0] - t[:, 0, 15]).mean()):.1f}, "
+      f"slowest workgroup {float((t[:, 0, 0] - t[:, 0, 15]).max()):.1f};  epilogue (last dS stored -> initial-state gradients stored): "
+      f"{float(t[:, -1, 15].max() - t[:, -1, 14].max()):.1f};  kernel entry -> end: {float(t[:, -1, 15].max() - t[:, 0, 15].min()):.1f}")
 print(f"token period: mean {float(per.mean()):.2f}  (tokens 2..{T - 2}: {float(per[2:-2].mean()):.2f})")
 s = slice(2, T - 2)
 names = [("wait for the attention barrier of the previous token", 0, 1), ("SW: dS W_attn_h partial tiles stored", 1, 2),
