@@ -66,6 +66,7 @@ struct DecArgs {
     float* hx;                           // [3][T+1][H/4][64][4]   h_l(t) in slot t + 1
     int xd_off, cx_off, sx_off, ex_bytes;   // byte offsets of xd [2][T][H/4][64][4], cx [T][Cw/4][64][4], sx [T][64][ldS]
     gb::XBar* bar;
+    unsigned* scnt;                      // [4] arrival counters of the score tiles, one per block of 16 questions, each on a 128-byte line of its own (null: a device-wide barrier behind the score phase)
     float* poison; unsigned* sticky_fail; unsigned* host_fail; unsigned expect_wg, max_spins;
     unsigned long long* trace;
 };
@@ -268,6 +269,16 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
         it_b = item / nchunks; it_chunk = item - it_b * nchunks;
     }
 
+    // question blocks (of 16) whose scores this workgroup's attention items read: bit r = block r (lane 0 polls for all waves)
+    unsigned need_rb = 0;
+    {
+        const int nt = B * chunks_t, nv = B * chunks_v, na = B * chunks_a;
+        if (B * chunks_t <= a.G) { if (g < nt) need_rb |= 1u << ((g / chunks_t) >> 4); }
+        else { for (int k = 0; k < 2; ++k) if (g + k * a.G < nt) need_rb |= 1u << (((g + k * a.G) / chunks_t) >> 4); }
+        if (B * chunks_v <= a.G) { if (g < nv) need_rb |= 1u << ((g / chunks_v) >> 4); }
+        else { for (int k = 0; k < 2; ++k) if (g + k * a.G < nv) need_rb |= 1u << (((g + k * a.G) / chunks_v) >> 4); }
+        if (g < na) need_rb |= 1u << ((g / chunks_a) >> 4);
+    }
     gb::Ctx bar;
     bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
     if (ok) ok = gb::sync(bar);
@@ -295,7 +306,20 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
             }
         }
         MMQG_DSTAMP(1)
-        gb::arrive(bar);
+        // The attention items of question b need the score rows of b's block of 16 questions only — the tiles of at most
+        // n_stile workgroups — not the whole chip: the score workgroups count their arrival per question block
+        // (point-to-point: stores drained by every wave, then ONE lane adds), and a workgroup's lane 0 polls the counters
+        // of the blocks its items belong to.  (a.scnt null: the device-wide barrier, as before.)
+        if (a.scnt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wg_s && tid == 0) {
+                const int rb0 = (g % s_split) * s_rbw;
+                for (int r = 0; r < s_rbw; ++r) gb::add_rlx(a.scnt + (rb0 + r) * gb::kLine, 1u);
+            }
+        } else {
+            gb::arrive(bar);
+        }
         // idle window of every wave with an attention item: the first 16 KB of its value rows are on their way while the score
         // tiles finish and the barrier turns (they do not depend on the scores)
         constexpr int kU = 8;
@@ -329,7 +353,17 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
                 dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, coff + min(first + u * groups, last) * rowb, 0, 0));
         };
         if (stream) { fetch(cur, r_lo + rgp); fetch(nxt, r_lo + rgp + kU * groups); }
-        ok = gb::wait(bar);
+        if (a.scnt) {
+            bool okp = true;
+            if (tid == 0) {
+                const unsigned target = (unsigned)n_stile * (unsigned)(t + 1);
+                for (int r = 0; r < 4 && okp; ++r)
+                    if ((need_rb >> r) & 1) okp = gb::spin_until_ge(a.scnt + r * gb::kLine, target, a.bar->fail, bar.max_spins);
+            }
+            ok = __syncthreads_and(okp);
+        } else {
+            ok = gb::wait(bar);
+        }
         if (!ok) break;
         MMQG_DSTAMP(2)
         // =========================================================== ATT: softmax + contexts of step t
@@ -480,11 +514,12 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
 
 inline int64_t align_up(int64_t v, int64_t al) { return (v + al - 1) / al * al; }
 
-struct WsLayout { int64_t bar, hx, xd, cx, sx, sticky, total; };
+struct WsLayout { int64_t bar, scnt, hx, xd, cx, sx, sticky, total; };
 WsLayout ws_layout(int T, int H, int Cw, int ldS) {
     WsLayout w;
     w.bar = 0;
-    w.hx = align_up((int64_t)sizeof(gb::XBar), 256);
+    w.scnt = align_up((int64_t)sizeof(gb::XBar), 128);                  // 4 counters, 128 bytes apart (zero-filled with the barrier block)
+    w.hx = align_up(w.scnt + 4 * 128, 256);
     w.xd = w.hx + (int64_t)3 * (T + 1) * kRows * H * 4;
     w.cx = w.xd + (int64_t)2 * T * kRows * H * 4;
     w.sx = w.cx + (int64_t)T * kRows * Cw * 4;
@@ -602,6 +637,12 @@ int decoder_seq_fwd_persistent(const mmqg_decoder_seq& d, hipStream_t s) {
     a.xd_off = (int)(wl.xd - wl.hx); a.cx_off = (int)(wl.cx - wl.hx); a.sx_off = (int)(wl.sx - wl.hx);
     a.ex_bytes = (int)(wl.sticky - wl.hx);
     a.bar = reinterpret_cast<gb::XBar*>(ws + wl.bar);
+    // MMQG_DEC_S_P2P=1 (opt-in A/B): per-question-block arrival counters behind the score phase instead of the
+    // device-wide barrier.  Measured at config 2 on one box (round 4): the wait behind the score tiles 5.38 us either way,
+    // attention window 14.14 (barrier) / 14.30 us (counters), token 41.3 us both: what a workgroup waits for there is the
+    // score workgroups' own chain (h_top load round + tile + store acknowledgement), not the barrier's 2.5 us.
+    static const bool s_p2p = [] { const char* e = getenv("MMQG_DEC_S_P2P"); return e && atoi(e) != 0; }();
+    a.scnt = s_p2p ? reinterpret_cast<unsigned*>(ws + wl.scnt) : nullptr;
     a.poison = d.hs + ((int64_t)2 * (T + 1) + T) * BH;
     a.sticky_fail = reinterpret_cast<unsigned*>(ws + wl.sticky);
     a.host_fail = persist_host_fail_word();

@@ -41,28 +41,13 @@ def _round4(n: int) -> int:
     return (n + 3) // 4 * 4
 
 
-_HIP = None
-
-
-def _registered_host_tensor(shape, dtype):
-    """A host tensor the device can read directly AND the CPU can fill at memcpy speed: ordinary (cached) memory registered
-    with hipHostRegister(portable | mapped) — ordinary cacheable pages, whatever the runtime does with hipHostMalloc memory.
-    Returns (tensor, device address).  The registration lives as long as the process (two small sets per trainer)."""
-    global _HIP
-    if _HIP is None:
-        _HIP = C.CDLL("libamdhip64.so")
-        _HIP.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
-        _HIP.hipHostGetDevicePointer.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint]
-    t = torch.empty(tuple(shape), dtype=dtype)
-    nbytes = max(t.numel() * t.element_size(), 1)
-    rc = _HIP.hipHostRegister(C.c_void_p(t.data_ptr()), nbytes, 3)          # hipHostRegisterPortable | hipHostRegisterMapped
-    if rc != 0:
-        raise _lib.BackendError(f"hipHostRegister failed ({rc})")
-    dp = C.c_void_p()
-    rc = _HIP.hipHostGetDevicePointer(C.byref(dp), C.c_void_p(t.data_ptr()), 0)
-    if rc != 0 or not dp.value:
-        raise _lib.BackendError(f"hipHostGetDevicePointer failed ({rc})")
-    return t, dp.value
+def _pinned_host_tensor(shape, dtype):
+    """Pinned (page-locked, device-mapped) host staging tensor from torch's host allocator, which also owns its lifetime.
+    Returns (tensor, device address).  (Registering ordinary tensors with hipHostRegister instead left the registration
+    behind when the trainer was collected: the next tensor malloc placed in that address range then failed its
+    host-to-device copy with hipErrorInvalidValue.)"""
+    t = torch.empty(tuple(shape), dtype=dtype).pin_memory()
+    return t, t.data_ptr()
 
 
 class BatchedTrainer:
@@ -483,7 +468,7 @@ class BatchedTrainer:
         Raw frames switch the HIP frame CNN on for the following forward / backward."""
         w, B, dev = self.ws, self.B, self.dev
         staged = None
-        if batch["frames"].device.type == "cpu" and os.environ.get("MMQG_HOST_BATCH", "mapped") != "copy":
+        if batch["frames"].device.type == "cpu" and os.environ.get("MMQG_HOST_BATCH", "dma") != "copy":
             batch, staged = self._stage_host_batch(batch)
         frames = batch["frames"]
         self._cnn_on = frames.dim() == 5
@@ -533,13 +518,15 @@ class BatchedTrainer:
 
     def _stage_host_batch(self, batch: dict):
         """A batch in HOST memory (what the reference's DataLoader hands over, train.py:144-162) on its way to the device
-        without a copy-engine call between two replays of the step graph: the tensors go into one of two pinned staging
-        sets (tensors that already are pinned are read in place), ONE kernel on a second stream reads them over PCIe
-        (``mmqg_fetch_mapped``) into a device staging set — beside the previous step, which the host is a step ahead of —
-        and the compute stream waits for that kernel only.  Returns (device batch, event to record after the pack
-        launch).  MMQG_HOST_BATCH=copy: blocking ``.to()`` copies (round 3); =async_memcpy: the same staging with
-        ``copy_(non_blocking=True)`` instead of the kernel (diagnostic: the variant that ran at 22 ms per step)."""
-        mode = os.environ.get("MMQG_HOST_BATCH", "mapped")
+        without blocking the host between two replays of the step graph: the tensors go into one of two pinned staging
+        sets with ONE plain memcpy each (tensors that already are pinned are read in place), the transfer runs on a
+        second stream — beside the previous step, which the host is a step ahead of — into a device staging set, and the
+        compute stream waits for that transfer only.  Returns (device batch, event to record after the pack launch).
+        MMQG_HOST_BATCH: ``dma`` (default) = asynchronous copies by the copy engine, which needs no CU and therefore runs
+        beside the persistent time loops; ``mapped`` = one kernel reads the staging set over PCIe (``mmqg_fetch_mapped``:
+        no copy-engine call at all, but it waits for CUs the persistent loops own); ``copy`` = blocking ``.to()`` copies
+        (round 3)."""
+        mode = os.environ.get("MMQG_HOST_BATCH", "dma")
         sig = tuple((k, tuple(batch[k].shape)) for k, _ in self._HOST_KEYS)
         hb = getattr(self, "_hb", None)
         if hb is None or hb["sig"] != sig:
@@ -547,7 +534,7 @@ class BatchedTrainer:
             for _ in range(2):
                 host, hptr = {}, {}
                 for k, dt in self._HOST_KEYS:
-                    host[k], hptr[k] = _registered_host_tensor(batch[k].shape, dt)
+                    host[k], hptr[k] = _pinned_host_tensor(batch[k].shape, dt)
                 devs = {k: torch.empty(batch[k].shape, dtype=dt, device=self.dev) for k, dt in self._HOST_KEYS}
                 hb["sets"].append(dict(host=host, hptr=hptr, dev=devs, ready=None, packed=None, keep=None))
             self._hb = hb
@@ -574,7 +561,7 @@ class BatchedTrainer:
         with torch.cuda.stream(hb["stream"]):
             if st["packed"] is not None:
                 hb["stream"].wait_event(st["packed"])        # the pack launch that read this device set two batches ago
-            if mode == "async_memcpy":
+            if mode != "mapped":
                 for k, _ in self._HOST_KEYS:
                     st["dev"][k].copy_(src[k], non_blocking=True)
             else:

@@ -719,11 +719,11 @@ def test_a_failed_persistent_decoder_launch_is_loud(mm):
     assert torch.equal(again, good)
 
 
-@pytest.mark.parametrize("mode", ["mapped", "copy"])
+@pytest.mark.parametrize("mode", ["dma", "mapped", "copy"])
 def test_batches_from_host_memory_give_the_same_steps(mm, mode, monkeypatch):
     """train.py:144-162 hands every batch over in HOST memory.  The trainer takes it from pageable or pinned host tensors
-    (mapped: one kernel reads the pinned staging set over PCIe on a second stream, two sets taking turns; copy: blocking
-    copies) and must do exactly the steps it does on device-resident batches: four different batches in a row, captured
+    (dma: pinned staging + copy engine on a second stream, two sets taking turns; mapped: one kernel reads the staging
+    set over PCIe; copy: blocking copies) and must do exactly the steps it does on device-resident batches: four different batches in a row, captured
     graph: the same losses bit for bit, the same weights to the last bits."""
     from mmqg_amd.synthetic import Workload, build_models, synthetic_batch
     monkeypatch.setenv("MMQG_HOST_BATCH", mode)

@@ -2,7 +2,7 @@
 """PCIe-inclusive training rate: the same steps as bench.py, but every step's batch starts in HOST memory (what the
 reference's DataLoader hands over, train.py:149-162) and is copied to the device inside the timed region.
 
-    python tools/host_batch_rate.py [workload] [steps] [modes: mapped,copy,async_memcpy]
+    python tools/host_batch_rate.py [workload] [steps] [modes: dma,mapped,copy]
 
 bench.py's `value` is measured with the batch resident in HBM; this is the figure beside it."""
 import os
@@ -37,7 +37,7 @@ for label, fn in (("torch copy_ into pinned", lambda: dst.copy_(src)),
           f"(torch threads {torch.get_num_threads()}, cpus visible {os.cpu_count()}, usable {len(os.sched_getaffinity(0))})", flush=True)
 hosts = [synthetic_batch(w, seed=i) for i in range(4)]          # four different batches, as a DataLoader would hand over
 variants = [("device-resident (bench.py)", None, [{k: v.cuda() for k, v in h.items()} for h in hosts])]
-for mode in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("mapped", "copy")):
+for mode in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("dma", "mapped", "copy")):
     variants.append((f"host, pageable [{mode}]", mode, hosts))
     variants.append((f"host, pinned   [{mode}]", mode, [{k: v.pin_memory() for k, v in h.items()} for h in hosts]))
 for label, mode, batches in variants:
