@@ -452,14 +452,45 @@ int gemm_f32_wgrad_group(const GemmProblem* probs, float* const* colsum, float* 
     constexpr int cap = 2 * MMQG_MAX_LAYERS + 4;
     GemmProblem big[cap], rest[cap];
     float* cs1[cap]; float* cs2[cap];
+    int src[cap];                       // index in probs of big[i]
+    bool took[cap] = {};                // probs[i] goes to the split-bf16 launch (with its column sums)
     int nb = 0, nr = 0;
     bool fused = n <= cap;
     for (int i = 0; i < n && fused; ++i) {
         const GemmProblem& q = probs[i];
         if (q.A && q.B && q.C && gemm_x3_wants(q.M, q.N, q.K)) {
-            big[nb] = q; cs1[nb] = colsum ? colsum[i] : nullptr; cs2[nb] = colsum2 ? colsum2[i] : nullptr; ++nb;
+            big[nb] = q; cs1[nb] = colsum ? colsum[i] : nullptr; cs2[nb] = colsum2 ? colsum2[i] : nullptr; src[nb] = i; took[i] = true; ++nb;
         } else {
             rest[nr++] = q;
+        }
+    }
+    // OPT-IN (MMQG_X3_PEEL=1).  One 256 x 128 tile per workgroup and CU: a group whose tiles just exceed the CU count pays a
+    // whole second round for the excess (the decoder's group at config 2: 264 tiles on 256 CUs — 8 of them from dW_attn).
+    // Peeling the smallest products back to the fp32 kernels (their column sums to a sweep of their own) brings the group
+    // under the CU count.  Measured (round 4, one box): the decoder's backward phase alone 1,424 -> 1,359 us, but the step
+    // 4.20-4.22 -> 4.23-4.24 ms: in the step the group runs beside the text encoder's weight gradients, which use the CUs
+    // the thin second round leaves idle, and the peeled products cost two more launches.
+    if (fused && nb > 1) {
+        const int slots = gemm_x3_slots();
+        auto tiles_of = [](const GemmProblem& q) { return ceil_div(q.M, 256) * ceil_div(q.N, 128); };
+        int total = 0;
+        for (int i = 0; i < nb; ++i) total += tiles_of(big[i]);
+        const int rounds = slots > 0 ? ceil_div(total, slots) : 1;
+        const int excess = slots > 0 ? total - (rounds - 1) * slots : 0;          // tiles in the last round
+        static const bool peel = [] { const char* e = getenv("MMQG_X3_PEEL"); return e && atoi(e) != 0; }();
+        if (rounds > 1 && excess * 8 <= total && peel) {
+            int peeled = 0;
+            while (peeled < excess && nb > 1) {
+                int best = 0;
+                for (int i = 1; i < nb; ++i)
+                    if (tiles_of(big[i]) < tiles_of(big[best])) best = i;
+                if (peeled + tiles_of(big[best]) > 2 * excess) break;
+                peeled += tiles_of(big[best]);
+                rest[nr++] = big[best];
+                took[src[best]] = false;
+                for (int i = best; i + 1 < nb; ++i) { big[i] = big[i + 1]; cs1[i] = cs1[i + 1]; cs2[i] = cs2[i + 1]; src[i] = src[i + 1]; }
+                --nb;
+            }
         }
     }
     if (fused && nb > 0) {
@@ -473,7 +504,7 @@ int gemm_f32_wgrad_group(const GemmProblem* probs, float* const* colsum, float* 
     for (int i = 0; i < n; ++i) {
         if (!colsum || !colsum[i]) continue;
         const GemmProblem& q = probs[i];
-        const bool taken = fused && q.A && q.B && q.C && gemm_x3_wants(q.M, q.N, q.K);
+        const bool taken = fused && i < cap && took[i];
         if (!taken) MMQG_TRY(colsum_add2(q.A, q.lda, q.K, q.M, colsum[i], colsum2 ? colsum2[i] : nullptr, s));
     }
     if (fused) return nr > 0 ? gemm_f32_grouped(MMQG_MN_MAJOR, MMQG_MN_MAJOR, rest, nr, s) : 0;

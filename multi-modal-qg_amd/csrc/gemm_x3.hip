@@ -643,6 +643,12 @@ int launch_pp(const X3Batch& b, int wgs, hipStream_t s) {
 
 namespace mmqg {
 
+// workgroup slots of one round of the ping-pong kernel (one 256 x 128 tile per CU); 0 = the kernel is not available
+int gemm_x3_slots() {
+    static const bool pp = [] { const char* e = getenv("MMQG_X3_PP"); return !e || atoi(e) != 0; }();
+    return pp ? x3_cus() : 0;
+}
+
 bool gemm_x3_enabled() {
     static const bool on = [] { const char* e = getenv("MMQG_GEMM_X3"); return !e || atoi(e) != 0; }();
     return on;

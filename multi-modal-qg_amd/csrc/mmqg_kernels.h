@@ -27,6 +27,7 @@ int gemm_f32_grouped(int a_layout, int b_layout, const GemmProblem* probs, int n
 // gemm_x3.hip: large products with fp32-exact operands split into bf16 pieces on the bf16 matrix cores.
 // gemm_x3_grouped: 0 = launched, 1 = not taken (fall back), < 0 = error; bias arrays nullable (per problem, per column)
 bool gemm_x3_wants(int M, int N, int K);
+int gemm_x3_slots();
 int gemm_x3_projection(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias, float* C,
                        int ldc, float* stats, int64_t stats_bytes, int* stats_tiles, hipStream_t s);
 // colsum / colsum2 (nullable arrays, nullable entries; m-major A only): out[m] += sum over k of A[k][m]
