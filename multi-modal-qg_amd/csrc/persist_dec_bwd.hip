@@ -51,9 +51,11 @@ constexpr int kRows = 64;
 constexpr int kU = 32;                   // hidden units per k-slice (x 4 gates = 128 k = 8 chunks of 16)
 constexpr int kChunks = 4 * kU / 16;     // 8
 constexpr int kMaxNS = 16;               // slices (H <= 512); the kernel is instantiated for NS = 4, 8, 16 (H = 128, 256, 512)
-constexpr int kMaxKR = 16;               // k-ranges of the score-gradient product
+constexpr int kMaxKR = 8;                // k-ranges of the score-gradient product
+constexpr int kSkip = -1;                // load_early: the ahead product is not asked for yet
+constexpr int kDirQ = 16;                // direct score-gradient product: at most 16 quads (64 positions) of a dS row per cell lane
 constexpr int kMaxD = 512;               // widest value row (16 lanes x 8 x 16 bytes)
-constexpr int kLdsBudget = 160 * 1024 - 1024;
+constexpr int kLdsBudget = 160 * 1024 - 256;      // (the grid barrier's 256 static bytes)
 constexpr int kFragF4 = kChunks * 4 * kRows;      // float4 of the dG fragment: 32 KB
 constexpr int kTraceSlots = 16;
 
@@ -63,7 +65,8 @@ struct DbArgs {
     int tpcL2, tpcL1, tpcL0, tpcA;           // late / ahead column tiles per workgroup
     int nchS, NKR, cpk;                      // score-gradient product: k-chunks, k-ranges, chunks per range
     int cpq, n_t, n_v, n_a;                  // attention plan: workgroups per question, wave-items per modality
-    int dbg;                                 // diagnostics (MMQG_PDB_DBG): 1 = wave 0 never loads ahead of its poll, 2 = no dgates stores (WRONG results)
+    int direct;                              // the score-gradient product runs inside the top layer's cell stage (no SW stage)
+    int dbg;                                 // diagnostics (MMQG_PDB_DBG): 1 = wave 0 never loads ahead of its poll, 2 = no dgates stores (WRONG results), 4 = print the plan once
     mmqg_attn_values v;
     const float* w_ihT1; const float* w_ihT2;                        // [H][4H] k-major copies
     const float* w_hhT0; const float* w_hhT1; const float* w_hhT2;   // [H][4H]
@@ -106,8 +109,13 @@ __device__ __forceinline__ f32x4 dropout_scale4(uint64_t seed, uint64_t stream_i
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f32x4 tanh4(const f32x4& v) { return f32x4{tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w)}; }
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ float sum16(float v) {      // over the 16 lanes that share lane >> 4
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+// sum over the 16 lanes that share lane >> 4 (a DPP row), in every lane: quad_perm [1,0,3,2], [2,3,0,1], then row_ror 4, 8
+// — no LDS crossbar, no index registers (ds_bpermute needed four of them per call site in a kernel that has none to spare)
+__device__ __forceinline__ float sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
     return v;
 }
 
@@ -147,7 +155,7 @@ __device__ __forceinline__ void load_early(Early& e, const Rsrc& rs, const float
     e.gg = *reinterpret_cast<const f32x4*>(gr + 2 * H); e.go = *reinterpret_cast<const f32x4*>(gr + 3 * H);
     e.cprev = *reinterpret_cast<const f32x4*>(cr); e.cnew = *reinterpret_cast<const f32x4*>(cr + BH);
     e.extra = xr ? *reinterpret_cast<const f32x4*>(xr) : zero4();
-    e.ahead = ldx(rs, aoff);                 // (first token: an out-of-range offset, reads as zero)
+    if (aoff != kSkip) e.ahead = ldx(rs, aoff);      // (first token: an out-of-range offset, reads as zero)
 }
 
 // Sum of the NS slices' partial tiles of an ahead product (dG_l(t) W_hh_l, [H/4 column quads][64 rows][4], contiguous per
@@ -268,7 +276,7 @@ __device__ __forceinline__ void att_stream(f32x4 (&b0)[kAttK], f32x4 (&b1)[kAttK
 #define MMQG_GSTAMP(slot)                                                                              \
     if (TRACE && tid == 0) stamps[t * kTraceSlots + (slot)] = (unsigned)wall_clock64();
 
-template <bool TRACE, int NS>
+template <bool TRACE, int NS, bool DIRECT>
 __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs a) {
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -289,7 +297,11 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     // ---- LDS: weight blocks of P2 | P1 | P0 (late tiles then ahead tiles each) | SW chunks | dG fragment (aliased: the
     // attention stage's dctx vectors, the score-gradient stage's k-part combine)
     const int wb2 = 0, wb1 = wb2 + (tpcL2 + tpcA) * 512, wb0 = wb1 + (tpcL1 + tpcA) * 512, wbs = wb0 + (tpcL0 + tpcA) * 512;
-    f32x4* frag = lds + wbs + a.cpk * 64;
+    // direct mode: [wave][k] quads W_attn_h[k][this wave's 4 units] in place of the SW stage's chunks
+    constexpr bool direct = DIRECT;
+    const int wbd = wbs;
+    const int Sd = (a.S + 3) & ~3;            // positions a cell lane multiplies (k >= S: zero weights, never past ldS <= ldD)
+    f32x4* frag = lds + wbs + (direct ? kWaves * Sd : a.cpk * 64);
     unsigned* stamps = reinterpret_cast<unsigned*>(frag + kFragF4);      // [T][kTraceSlots], stamped instantiation only
     if (TRACE) for (int i = tid; i < a.T * kTraceSlots; i += kThreads) stamps[i] = 0u;
     const unsigned t_entry = TRACE ? (unsigned)wall_clock64() : 0u;      // (slot 15 of the first token: kernel entry, before the weights are read)
@@ -343,7 +355,15 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     // score-gradient product: workgroup (sl, cg) owns column tile 2 sl + (cg & 1) and k-range cg >> 1
     const int sw_tile = 2 * sl + (cg & 1), sw_kr = cg >> 1;
     const int sw_c0 = sw_kr * a.cpk;
-    const int sw_n = (cellwg && sw_kr < NKR) ? max(0, min(a.cpk, a.nchS - sw_c0)) : 0;
+    const int sw_n = (!direct && cellwg && sw_kr < NKR) ? max(0, min(a.cpk, a.nchS - sw_c0)) : 0;
+    if (direct) {
+        // (rows k >= S of the transposed copy are zero by contract)
+        for (int idx = tid; idx < kWaves * Sd; idx += kThreads) {
+            const int w = idx / Sd, k = idx - w * Sd;
+            const float* src = a.w_attn_hT + (int64_t)(kU * sl + 4 * w) * a.ldS + k;
+            lds[wbd + idx] = f32x4{src[0], src[a.ldS], src[2 * a.ldS], src[3 * a.ldS]};
+        }
+    }
     for (int idx = tid; idx < sw_n * 64; idx += kThreads) {
         const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
         const int k = 16 * (sw_c0 + c) + 4 * kq, n = 16 * sw_tile + i;
@@ -354,6 +374,9 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     }
 
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.ex, 0, a.ex_bytes, 0x00020000);
+    // (direct mode reads the dS rows themselves; quads past the row through an out-of-range offset)
+    const auto rd = __builtin_amdgcn_make_buffer_rsrc(a.dscores, 0, T * B * a.ldD * 4, 0x00020000);
+    const int nq_dir = Sd / 4;
 
     // ---- cell-lane role: wave = unit quad (units 32 sl + 4 wave .. + 3), lane = row
     const int u0 = kU * sl + 4 * wave;
@@ -420,7 +443,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
         MMQG_GSTAMP(0)
         const int tok = t * tok_stride, tok1 = (t + 1) * tok_stride;
         // =================================================== SW: partial tiles of dS(t+1) W_attn_h (feeds dh_2(t))
-        if (t + 1 < T) {
+        if (!direct && t + 1 < T) {
             if (pend) { ok = gb::wait(bar); pend = false; }
             if (!ok) break;
             MMQG_GSTAMP(1)
@@ -470,19 +493,29 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             const float* cr = a.cs + (((int64_t)l * (T + 1) + t) * B + rowc) * H + u0;
             const float* xr = l == 2 ? a.dhtop + ((int64_t)t * B + rowc) * H + u0 : nullptr;
             const int aoff = t + 1 < T ? tok1 + r_off + l * r_bytes + ((8 * sl + wave) * kRows + row) * 16 : kOob;
+            // (direct mode: one barrier fewer per token lies between the window that sums the ahead product and this stage —
+            // the sum is only complete at the barrier this stage waits for, so it is asked for with the late operand)
+            const int aoff_early = direct ? kSkip : aoff;
             // (... unless this workgroup arrived last in its XCC: that lane 0 then releases the XCC, and its first poll would
             // wait for the loads)
             const bool early_now = cellwg && (wave != 0 || !pend || (!(a.dbg & 1) && !__builtin_amdgcn_readfirstlane((int)bar.leader)));
-            if (early_now) load_early(e, rs, gr, cr, xr, H, BH, aoff);
+            if (early_now) load_early(e, rs, gr, cr, xr, H, BH, aoff_early);
             if (pend) { ok = gb::wait(bar); pend = false; }
             MMQG_GSTAMP(3 + 3 * ph_i)
-            if (cellwg && !early_now) load_early(e, rs, gr, cr, xr, H, BH, aoff);
+            if (cellwg && !early_now) load_early(e, rs, gr, cr, xr, H, BH, aoff_early);
             if (!ok) break;
             if (cellwg) {
                 // ---- the late operand: partial tiles of the product that came down the chain
-                constexpr int NLATE = kMaxKR > NS ? kMaxKR : NS;
+                constexpr int NLATE = kDirQ > NS ? kDirQ : NS;
                 f32x4 late[NLATE];
-                if (l == 2) {
+                if (direct) e.ahead = ldx(rs, aoff);
+                if (l == 2 && direct) {
+                    // this row of dS(t+1), 16 bytes at a time (the first token has none: zeros)
+                    const int base = ((t + 1) * B + rowc) * a.ldD * 4;
+                    const int n = t + 1 < T ? nq_dir : 0;
+#pragma unroll
+                    for (int i = 0; i < kDirQ; ++i) late[i] = ldx(rd, i < n ? base + 16 * i : kOob);
+                } else if (l == 2) {
                     // (k-ranges past NKR, and the first token, which has no dS(t+1): out-of-range offsets read as zero)
                     const int base = tok1 + sw_off + (((2 * sl + (wave >> 2)) * NKR) * 4 + (wave & 3)) * 1024;
                     const int n = t + 1 < T ? NKR : 0;
@@ -493,10 +526,25 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
 #pragma unroll
                     for (int i = 0; i < NS; ++i) late[i] = ldxs(rs, row * 16, base + i * pq * 1024);
                 }
+                // (all of them in flight before the first is used: left to itself the scheduler pairs every load with its add —
+                // a load, s_waitcnt vmcnt(0), an add, sixteen times over, i.e. sixteen L2 round trips in a row on the chain)
+                __builtin_amdgcn_sched_barrier(0);
                 f32x4 pi = zero4();
                 const f32x4 ph = e.ahead;
+                if (l == 2 && direct) {
+                    // dS(t+1)[row][:] W_attn_h[:][this wave's 4 units]: the weights are wave-uniform LDS reads
+                    const f32x4* dw = lds + wbd + wave * Sd;
 #pragma unroll
-                for (int i = 0; i < (l == 2 ? kMaxKR : NS); ++i) pi += late[i];
+                    for (int i = 0; i < kDirQ; ++i)
+                        if (i < nq_dir) {
+                            pi += late[i].x * dw[4 * i] + late[i].y * dw[4 * i + 1];
+                            pi += late[i].z * dw[4 * i + 2] + late[i].w * dw[4 * i + 3];
+                            asm volatile("" ::: "memory");      // (four weight quads at a time: hoisted, the 64 reads take 256 registers)
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < (l == 2 ? kMaxKR : NS); ++i) pi += late[i];
+                }
                 if (l < 2 && a.drop)
                     pi *= dropout_scale4(seed, a.stream_base + (uint64_t)l * T + t, (uint64_t)((int64_t)row * H + u0), a.drop_p);
                 // ---- cell backward of (row, 4 units)
@@ -543,14 +591,15 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             // in P2's window and drained at the arrival to P1's barrier, which this workgroup has passed — by the last wave,
             // whose loads fly while it multiplies; then the gate gradients for the hoisted weight-gradient GEMMs (every
             // workgroup of the slice a few rows; wave 1 also stores wave 0's quad)
-            const bool red_on = l == 0 && wave == kWaves - 1 && red_cnt > 0;
+            const bool red_win = l == 0 || (direct && l == 2);      // windows in which the last wave sums an ahead product
+            const bool red_on = red_win && wave == kWaves - 1 && red_cnt > 0;
             {
                 // the window's product waves of this row block: not wave 0 (it polls), and in P0's window not the last wave
                 // (it sums); their column parts are renumbered
                 int part = -1, nparts = 0;
                 for (int p = 0; p < KP; ++p) {
                     const int w = rb + RB * p;
-                    const bool act = w != 0 && !(l == 0 && w == kWaves - 1 && red_cnt > 0);
+                    const bool act = w != 0 && !(red_win && w == kWaves - 1 && red_cnt > 0);
                     if (w == wave && act) part = nparts;
                     nparts += act ? 1 : 0;
                 }
@@ -558,7 +607,11 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
                     products(rs, frag, lds + wb + tpcL * 512 + ln, nA, part, nparts, rb, j, q,
                              tok + pl_off + (sl * a_quads + a_first + 4 * cg * tpcA + q) * 1024 + (rb * 16 + j) * 16, 4 * 1024);
             }
-            if (red_on) reduce_ahead<NS>(rs, tok + nlate21 * 4 * 1024, pq * 1024, tok + r_off + 2 * r_bytes, red_o0, red_cnt, ln);
+            if (red_on && l == 0) reduce_ahead<NS>(rs, tok + nlate21 * 4 * 1024, pq * 1024, tok + r_off + 2 * r_bytes, red_o0, red_cnt, ln);
+            // (direct mode, P2's window: layer 0's ahead product of token t + 1 — stored in P0's window, drained before the
+            // attention stage's barrier, which this workgroup has passed; the SW stage's window did this)
+            if (red_on && l == 2 && t + 1 < T)
+                reduce_ahead<NS>(rs, tok1 + p0x_off, (H / 4) * 1024, tok1 + r_off, red_o0, red_cnt, ln);
             // the gate gradients for the hoisted weight-gradient GEMMs: every workgroup of the slice stores dg_rows rows, ONE
             // wave reads them back from the fragment so that 8 lanes cover a whole 128-byte line (32 units of a gate); the
             // scattered 16-byte stores of the cell lanes took 2-3 us to be acknowledged, in front of the next stage's loads
@@ -609,6 +662,12 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             if (!ok) break;
             MMQG_GSTAMP(12)
             if (cx_on && !cx_now) cxv = *reinterpret_cast<const f32x4*>(cxp);
+            // The carries of the top layer sit out this stage in the dG fragment, which is free between this stage's wait
+            // (the workgroup has read it for the last time) and the next product: with two batches of value rows and the
+            // slices' dctx parts in flight the stage was 4 registers short, and ONE spilled quad gives the kernel a scratch
+            // allocation that every launch has to set up.
+            f32x4* park = frag + 512;
+            park[tid] = dc2; park[kThreads + tid] = dhc2;
             // dctx(t)[qb][modality columns] = sum over the slices' row-major partial blocks; 128 threads per modality
             float* dotp = reinterpret_cast<float*>(frag + 3 * 128);       // [8] per-wave parts of ctx . dctx
             if (v_need) {
@@ -637,6 +696,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
                 if (lg == 3) att_stream<3>(cur, nxt, a_cur, a_nxt, rv, arow, dsr, vec, dot, it_r0, it_r1, n_stream, rg, cl, last, D, Dq, oob);
                 else att_stream<1>(cur, nxt, a_cur, a_nxt, rv, arow, dsr, vec, dot, it_r0, it_r1, n_stream, rg, cl, last, D, Dq, oob);
             }
+            dc2 = park[tid]; dhc2 = park[kThreads + tid];
             MMQG_GSTAMP(14)
             gb::arrive(bar);
             pend = true;
@@ -681,7 +741,15 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             for (int l = 0; l < 3; ++l) {
                 f32x4 sum = l == 2 ? dhc2 : (l == 1 ? dhc1 : dhc0);
                 sum += ldx(rs, r_off + l * r_bytes + ((8 * sl + wave) * kRows + row) * 16);
-                if (l == 2) {
+                if (l == 2 && direct) {
+                    const f32x4* dw = lds + wbd + wave * Sd;
+                    const int base = min(row, B - 1) * a.ldD * 4;
+                    for (int i = 0; i < nq_dir; ++i) {
+                        const f32x4 x = ldx(rd, base + 16 * i);
+                        sum += x.x * dw[4 * i] + x.y * dw[4 * i + 1];
+                        sum += x.z * dw[4 * i + 2] + x.w * dw[4 * i + 3];
+                    }
+                } else if (l == 2) {
                     const int sb = sw_off + (((2 * sl + (wave >> 2)) * NKR) * 4 + (wave & 3)) * 1024 + row * 16;
                     for (int i = 0; i < NKR; ++i) sum += ldx(rs, sb + i * 4096);
                 }
@@ -708,11 +776,12 @@ inline int64_t align_up(int64_t v, int64_t al) { return (v + al - 1) / al * al; 
 
 // everything the kernel's geometry follows from (shape + grid size)
 struct Plan {
-    int NS, GS, RB, tpcL2, tpcL1, tpcL0, tpcA, nchS, NKR, cpk, cpq, n_t, n_v, n_a, lds_bytes;
+    int NS, GS, RB, tpcL2, tpcL1, tpcL0, tpcA, nchS, NKR, cpk, cpq, n_t, n_v, n_a, lds_bytes, direct;
     int64_t szP, szP0x, szD0, szSW, szR, tok_stride;
 };
 
 bool make_plan(int B, int H, int Cw, int ldS, const mmqg_attn_values& v, int G, Plan& p) {
+    const int Sd = (v.Lt + 2 * v.Lav + 3) & ~3;
     if (H % kU || H < 128 || H / kU > kMaxNS || Cw % 16 || B < 1 || B > kRows || B > G) return false;
     p.NS = H / kU;
     if (p.NS != 4 && p.NS != 8 && p.NS != 16) return false;       // the instantiated slice counts: H = 128, 256, 512
@@ -727,7 +796,13 @@ bool make_plan(int B, int H, int Cw, int ldS, const mmqg_attn_values& v, int G, 
     p.NKR = std::min(std::min(p.GS / 2, p.nchS), kMaxKR);
     p.cpk = ceil_div(p.nchS, p.NKR);
     p.NKR = ceil_div(p.nchS, p.cpk);
-    p.lds_bytes = ((p.tpcL2 + p.tpcL1 + p.tpcL0 + 3 * p.tpcA) * 512 + p.cpk * 64 + kFragF4) * 16;
+    // Short score rows: every cell lane of the top layer multiplies its row of dS(t+1) itself, which takes the SW stage
+    // and its barrier out of the token (MMQG_PDB_SW_STAGE=1 keeps the stage: the A/B switch).
+    static const bool keep_sw = [] { const char* e = getenv("MMQG_PDB_SW_STAGE"); return e && atoi(e) != 0; }();
+    const int w_f4 = (p.tpcL2 + p.tpcL1 + p.tpcL0 + 3 * p.tpcA) * 512;
+    const int lds_direct = (w_f4 + kWaves * Sd + kFragF4) * 16;
+    p.direct = (!keep_sw && Sd <= 4 * kDirQ && Sd <= ldS && lds_direct <= kLdsBudget) ? 1 : 0;
+    p.lds_bytes = p.direct ? lds_direct : (w_f4 + p.cpk * 64 + kFragF4) * 16;
     if (p.lds_bytes > kLdsBudget) return false;
     // attention: cpq workgroups (7 worker waves each) per question, shared out over the modalities by bytes per wave
     p.cpq = G / B;
@@ -826,15 +901,19 @@ int decoder_seq_bwd_persistent(const mmqg_decoder_seq& d, const mmqg_decoder_seq
     if ((v.mask_mode == MMQG_MASK_INTENDED || v.zero_past_len) && !(v.text_len && v.av_len)) return 1;
     // one instantiation per slice count (the slice loops are compile-time: a run-time bound made hipcc branch around every load)
     typedef void (*KernelFn)(DbArgs);
-    const KernelFn fns[3][2] = {{decoder_persist_bwd_kernel<false, 4>, decoder_persist_bwd_kernel<true, 4>},
-                                {decoder_persist_bwd_kernel<false, 8>, decoder_persist_bwd_kernel<true, 8>},
-                                {decoder_persist_bwd_kernel<false, 16>, decoder_persist_bwd_kernel<true, 16>}};
-    const int ki = p.NS == 4 ? 0 : (p.NS == 8 ? 1 : (p.NS == 16 ? 2 : -1));
-    if (ki < 0) return 1;
+    const KernelFn fns[6][2] = {{decoder_persist_bwd_kernel<false, 4, false>, decoder_persist_bwd_kernel<true, 4, false>},
+                                {decoder_persist_bwd_kernel<false, 8, false>, decoder_persist_bwd_kernel<true, 8, false>},
+                                {decoder_persist_bwd_kernel<false, 16, false>, decoder_persist_bwd_kernel<true, 16, false>},
+                                {decoder_persist_bwd_kernel<false, 4, true>, decoder_persist_bwd_kernel<true, 4, true>},
+                                {decoder_persist_bwd_kernel<false, 8, true>, decoder_persist_bwd_kernel<true, 8, true>},
+                                {decoder_persist_bwd_kernel<false, 16, true>, decoder_persist_bwd_kernel<true, 16, true>}};
+    const int ns_i = p.NS == 4 ? 0 : (p.NS == 8 ? 1 : (p.NS == 16 ? 2 : -1));
+    if (ns_i < 0) return 1;
+    const int ki = ns_i + (p.direct ? 3 : 0);
     static int attr_set = 0;
     if (attr_set == 0) {
         hipError_t e = hipSuccess;
-        for (int i = 0; i < 6 && e == hipSuccess; ++i)
+        for (int i = 0; i < 12 && e == hipSuccess; ++i)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i / 2][i % 2]), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
         if (e != hipSuccess) (void)hipGetLastError();
         attr_set = e == hipSuccess ? 1 : -1;
@@ -863,7 +942,7 @@ int decoder_seq_bwd_persistent(const mmqg_decoder_seq& d, const mmqg_decoder_seq
     a.T = T; a.B = B; a.H = H; a.Cw = Cw; a.S = S; a.ldS = d.ld_attn; a.ldD = g.ld_ds; a.G = G;
     a.NS = p.NS; a.GS = p.GS; a.RB = p.RB;
     a.tpcL2 = p.tpcL2; a.tpcL1 = p.tpcL1; a.tpcL0 = p.tpcL0; a.tpcA = p.tpcA;
-    a.nchS = p.nchS; a.NKR = p.NKR; a.cpk = p.cpk;
+    a.nchS = p.nchS; a.NKR = p.NKR; a.cpk = p.cpk; a.direct = p.direct;
     a.cpq = p.cpq; a.n_t = p.n_t; a.n_v = p.n_v; a.n_a = p.n_a;
     { static const int dbg = [] { const char* e = getenv("MMQG_PDB_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
     a.v = v;
@@ -887,6 +966,12 @@ int decoder_seq_bwd_persistent(const mmqg_decoder_seq& d, const mmqg_decoder_seq
     a.trace = nullptr;
     const int trace_lds = T * kTraceSlots * 4;
     if (g_gtrace_buf && (int64_t)G * T * kTraceSlots <= g_gtrace_words && p.lds_bytes + trace_lds <= kLdsBudget) a.trace = g_gtrace_buf;
+    if (a.dbg & 4) {
+        static bool said = false;
+        if (!said) fprintf(stderr, "[mmqg] decoder bwd plan: G %d NS %d GS %d RB %d tiles %d %d %d +%d, direct %d, lds %d (+%d stamps), kernel %d/%d\n",
+                           G, p.NS, p.GS, p.RB, p.tpcL2, p.tpcL1, p.tpcL0, p.tpcA, p.direct, p.lds_bytes, a.trace ? trace_lds : 0, ki, a.trace ? 1 : 0);
+        said = true;
+    }
     hipLaunchKernelGGL(fns[ki][a.trace ? 1 : 0], dim3(G), dim3(kThreads), (size_t)(p.lds_bytes + (a.trace ? trace_lds : 0)), s, a);
     g_dec_bwd_launches += 1;
     persist_end(s);

@@ -50,6 +50,7 @@ tr.g_dec.phase = 0
 assert lib.mmqg_decoder_persist_bwd_launch_count() == n0 + 13, "the persistent decoder backward loop did not take this shape"
 raw = buf.view(G, T, NSLOT).cpu()
 assert int((raw[:, :, 0] != 0).sum()) == G * T, "the stamped instantiation did not run (no room for the stamps in LDS?)"
+direct_mode = int((raw[:, :T - 1, 1] != 0).sum()) == 0        # no SW stage stamps
 raw = (raw - raw[:, T - 1:T, 15:16].min()) % (1 << 32)      # low 32 bits of the 100 MHz counter, relative to the first start
 t = raw.double() * 0.01                                   # us; token index = t (the loop runs T-1 .. 0)
 t = t.flip(1)                                             # in execution order
@@ -67,6 +68,10 @@ names = [("wait for the attention barrier of the previous token", 0, 1), ("SW: d
          ("barrier after P2 (window: ahead product)", 5, 6), ("P1: late partials summed, cell backward", 6, 7), ("P1: late product stored", 7, 8),
          ("barrier after P1 (window: ahead product)", 8, 9), ("P0: late partials summed, cell backward", 9, 10), ("P0: late product (dctx) stored", 10, 11),
          ("barrier after P0 (window: ahead product, reduce)", 11, 12), ("ATT: dctx summed over the slices", 12, 13), ("ATT: value rows streamed, dS stored", 13, 14)]
+if direct_mode:
+    # the score-gradient product ran inside P2 (short score rows): no SW stage, the attention barrier is waited for by P2
+    print("direct score-gradient product: no SW stage")
+    names = [("barrier after the previous token's attention stage (+ early loads of P2)", 0, 3)] + names[3:]
 for name, i0, i1 in names:
     d = t[:, s, i1] - t[:, s, i0]
     print(f"{name:56s} mean {float(d.mean()):6.2f}   slowest workgroup per token {float(d.max(0).values.mean()):6.2f}   fastest {float(d.min(0).values.mean()):6.2f}")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round profile set (run on the GPU box from the repo root):  bash tools/profile_round.sh r03 [workloads...]
+# Round profile set (run on the GPU box from the repo root):  bash tools/profile_round.sh r04 [workloads...]
 # For every workload: the bench line, rocprofv3 kernel-trace stats of (a) the step launches alone (--kernel-iters 0:
 # the CSV the in-step attention figure is recomputed from) and (b) the default command, the two PMC passes of the
 # attention kernel (FETCH_SIZE / WRITE_SIZE, collected separately), and the per-phase times.
@@ -36,6 +36,16 @@ for W in $WL; do
   rm -rf $OUT/stats_$W
   python3 tools/phase_times.py $W > $OUT/phase_times_$W.txt 2>/dev/null
   python3 tools/persist_dec_trace.py $W > $OUT/persist_dec_trace_$W.txt 2>/dev/null || rm -f $OUT/persist_dec_trace_$W.txt
+  python3 tools/persist_dec_bwd_trace.py $W > $OUT/persist_dec_bwd_trace_$W.txt 2>/dev/null || rm -f $OUT/persist_dec_bwd_trace_$W.txt
+  python3 tools/host_batch_rate.py $W 50 2>/dev/null | grep "^$W " >> $OUT/host_batch_rate.txt
 done
+# one rank through the data-parallel schedule over RCCL (the self-launcher), with and without the CUs reserved for RCCL, and
+# the plain step on the same box
+python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --kernel-iters 0 > $OUT/bench_config2_same_box.json 2>/dev/null
+MMQG_FORCE_DP=1 MMQG_BENCH_FORCE_LAUNCH=1 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --kernel-iters 0 > $OUT/bench_config2_force_dp.json 2>/dev/null
+MMQG_DP_RESERVE_CUS=0 MMQG_FORCE_DP=1 MMQG_BENCH_FORCE_LAUNCH=1 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --kernel-iters 0 > $OUT/bench_config2_force_dp_noreserve.json 2>/dev/null
+MMQG_X3_MAX_SPLIT=1 python3 tools/x3_fixed_cost.py > $OUT/x3_fixed_cost.txt 2>/dev/null
+MMQG_X3_MAX_SPLIT=1 MMQG_X3_DWORD_EPILOGUE=1 python3 tools/x3_fixed_cost.py >> $OUT/x3_fixed_cost.txt 2>/dev/null
+MMQG_X3_MAX_SPLIT=1 MMQG_X3_BAL=1 python3 tools/x3_fixed_cost.py >> $OUT/x3_fixed_cost.txt 2>/dev/null
 cp profiles/attn_in_step.json profiles/attn_traffic.json $OUT/
 echo profile set done
