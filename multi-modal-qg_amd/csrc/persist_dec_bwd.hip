@@ -450,12 +450,25 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
             MMQG_LANE_ROLES
             if (sw_n > 0 && rb_on) {
                 // wave (rb, cp): chunks cp, cp + KP, ... of this workgroup's k-range; lane (j: row, q: k quad)
-                const float* ds = a.dscores + ((int64_t)(t + 1) * B + min(rb * 16 + j, B - 1)) * a.ldD;
+                // (the wave's dS quads all asked for before the first product: one L2 round trip, not one per chunk)
+                const int dsrow = ((t + 1) * B + min(rb * 16 + j, B - 1)) * a.ldD * 4;
+                constexpr int kPre = 4;
+                f32x4 xs[kPre];
+#pragma unroll
+                for (int u = 0; u < kPre; ++u) {
+                    const int c = cp + u * KP, k = 16 * (sw_c0 + c) + 4 * q;
+                    xs[u] = ldx(rd, (c < sw_n && k < a.ldS) ? dsrow + 4 * k : kOob);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc0 = zero4(), acc1 = zero4();
-                for (int c = cp; c < sw_n; c += KP) {
+#pragma unroll
+                for (int u = 0; u < kPre; ++u) {
+                    const int c = cp + u * KP;
+                    if (c < sw_n) mfma_chunk(acc0, acc1, lds[wbs + c * 64 + ln], xs[u]);
+                }
+                for (int c = cp + kPre * KP; c < sw_n; c += KP) {
                     const int k = 16 * (sw_c0 + c) + 4 * q;
-                    f32x4 x = zero4();
-                    if (k < a.ldS) x = *reinterpret_cast<const f32x4*>(ds + k);
+                    const f32x4 x = ldx(rd, k < a.ldS ? dsrow + 4 * k : kOob);
                     mfma_chunk(acc0, acc1, lds[wbs + c * 64 + ln], x);
                 }
                 frag[wave * 64 + ln] = acc0 + acc1;

@@ -714,6 +714,14 @@ class BatchedTrainer:
         pair = part == "all" and self.chain_first and bool(self.g_text.persist_ws) and not self.distributed and \
             os.environ.get("MMQG_NO_BWD_PAIR", "0") != "1"
         pair_done = []
+        # Single GPU, captured step: Adam rides inside the step graph, one segment at a time as its gradients become final
+        # and on whichever stream is free — the text encoder's behind its weight gradients on the chain stream (beside the
+        # decoder's weight-gradient group on the other), the decoder's on the chain stream as soon as the other stream has
+        # its last gradient (beside the frame encoder's weight gradients), the small rest behind the join.  Adam is
+        # HBM-bound, the GEMMs beside it are matrix-bound and leave CUs empty (160 and 264 workgroups of one per CU); in a
+        # tail of their own the optimizer launches were 136 us of a 4.0 ms step.
+        inline_adam = part == "all" and self._early_adam and self._inline_adam_ok()
+        dec_done = []
 
         def enc_side(which: str = "both"):   # decoder weight gradients ("s1"), frame encoder backward ("s2")
             s2 = ops._stream()
@@ -726,6 +734,8 @@ class BatchedTrainer:
                 check(lib.mmqg_decoder_seq_bwd(C.byref(self.d_dec), C.byref(self.g_dec), s2), "decoder_seq_bwd(wgrad)")
                 self.g_dec.phase = 0
                 ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
+                if inline_adam:
+                    dec_done.append(self._mark())     # the decoder segment's gradients are final: its Adam runs on the other stream
                 if self.distributed and not torch.cuda.is_current_stream_capturing():
                     # the decoder bucket (everything but the embedding) is final here: start its all-reduce
                     # from the side stream so it runs beside the text encoder's backward
@@ -740,10 +750,10 @@ class BatchedTrainer:
                     check(lib.mmqg_frame_cnn_bwd(C.byref(self.d_cnn), C.byref(self.g_cnn), s2), "frame_cnn_bwd")
                 if self.distributed and not torch.cuda.is_current_stream_capturing():
                     self.reducer.reduce("vid")          # frame encoder gradients are final too
-            if which == "both" and self._early_adam:
-                # single GPU, captured step: the decoder's and the frame encoder's gradients are final here, and nothing
-                # later in the step reads their parameters — their Adam (HBM-bound) runs on this branch beside the text
-                # encoder's backward (latency-bound) instead of after it
+            if which == "both" and self._early_adam and not inline_adam:
+                # (MMQG_INLINE_ADAM=0, the round-3 arrangement) single GPU, captured step: the decoder's and the frame
+                # encoder's gradients are final here, and nothing later in the step reads their parameters — their Adam
+                # runs at the end of this branch, the rest in a graph of its own behind the step
                 self._adam("early")
 
         def enc_chain():             # text encoder backward: the rest of the dependent chain
@@ -767,10 +777,19 @@ class BatchedTrainer:
             enc_chain()
         elif self.chain_first:
             mark = self._mark()
+            if inline_adam:
+                self._adam("begin")
             enc_chain()
+            if inline_adam:
+                self._adam("text")          # (behind the last persistent launch of the step: the guard is refreshed here)
             with self._fork_from(mark):
                 enc_side()
+            if inline_adam:
+                torch.cuda.current_stream().wait_event(dec_done[0])
+                self._adam("dec")
             self._join()
+            if inline_adam:
+                self._adam("end")
         else:
             with self._fork():
                 enc_side()
@@ -843,6 +862,11 @@ class BatchedTrainer:
             self._tr_jobs = arr
         check(_lib.load().mmqg_transpose_f32_batch(self._tr_jobs, len(self._tr_jobs), ops._stream()), "transpose_f32_batch")
 
+    def _inline_adam_ok(self) -> bool:
+        """The captured single-GPU step may carry its optimizer launches inside the step graph (MMQG_INLINE_ADAM=0: the
+        round-3 arrangement, decoder + frame encoder at the end of the side branch and the rest in a graph of its own)."""
+        return self.chain_first and not self._serial and os.environ.get("MMQG_INLINE_ADAM", "1") != "0"
+
     def _adam_split(self) -> int:
         """First element of the 'rest' bucket (0: the flat layout has no dec | vid | rest split)."""
         bk = self.reducer.buckets
@@ -856,6 +880,35 @@ class BatchedTrainer:
         b1, b2 = self.betas
         scale = 1.0 / self.world
         split = self._adam_split()
+        if part in ("begin", "text", "dec", "end"):
+            # the single-GPU graph step's in-graph optimizer (see _loss_and_backward): 'begin' advances Adam's step
+            # number, 'text' refreshes the guard and updates the text encoder, 'dec' the decoder, 'end' the frame
+            # encoder and the embedding (twice: the reference's two optimizers) and closes the step
+            bk = self.reducer.buckets
+            d0, v0, v1 = bk["dec"][0], bk["vid"][0], bk["rest"][0]
+            e0, e1 = self.segments["emb"]
+            guard = self.guard_dev.data_ptr()
+
+            def upd(lo, hi, m=None, v=None, what="adam_step"):
+                if hi <= lo:
+                    return
+                check(lib.mmqg_adam_step_guarded(self.flat_p.data_ptr() + 4 * lo, self.flat_g.data_ptr() + 4 * lo,
+                                                 (self.flat_m.data_ptr() + 4 * lo) if m is None else m,
+                                                 (self.flat_v.data_ptr() + 4 * lo) if v is None else v, hi - lo,
+                                                 self.lr, b1, b2, self.eps, self.adam_dev.data_ptr(), scale, guard, s), what)
+            if part == "begin":
+                check(lib.mmqg_counter_add(self.adam_dev.data_ptr(), 1, s), "counter_add")
+            elif part == "text":
+                check(lib.mmqg_persist_guard_refresh(guard, s), "persist_guard_refresh")
+                upd(v1, e0)
+            elif part == "dec":
+                upd(d0, v0)
+            else:
+                upd(v0, v1)
+                upd(e0, self.n_params)
+                upd(e0, e1, self.emb_m2.data_ptr(), self.emb_v2.data_ptr(), "adam_step(embedding, 2nd optimizer)")
+                check(lib.mmqg_counter_add(self.step_dev.data_ptr(), 1, s), "counter_add")
+            return
         if part in ("all", "early"):
             check(lib.mmqg_counter_add(self.adam_dev.data_ptr(), 1, s), "counter_add")
         # one device thread copies the persistent kernels' failure word (pinned host memory) into the guard the optimizer
@@ -982,7 +1035,8 @@ class BatchedTrainer:
             self._graph = self._graphs[parts[0]]
             self._early_adam = False
             self._graph_early_adam = split_early
-            for part in (("early", "late") if dp else (("late",) if split_early else ("all",))):
+            self._graph_inline_adam = split_early and self._inline_adam_ok()
+            for part in (("early", "late") if dp else (() if self._graph_inline_adam else (("late",) if split_early else ("all",)))):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                     self._adam(part)
@@ -991,7 +1045,8 @@ class BatchedTrainer:
         if not dp:
             G["all"].replay()
             self._count_bn_batches()
-            G["adam_late" if self._graph_early_adam else "adam_all"].replay()
+            if not self._graph_inline_adam:         # (inline: every optimizer launch is a node of the step graph)
+                G["adam_late" if self._graph_early_adam else "adam_all"].replay()
             return self.ws["loss"]
         main = torch.cuda.current_stream()
         G["dec"].replay()

@@ -526,7 +526,12 @@ def test_kernel_families_give_the_same_gradients_at_bench_size(mm, tmp_path):
                              # encoder | text encoder), the bucket all-reduces over RCCL between them, early / late Adam,
                              # the frame LSTM's backward off the paired launch, the text encoder's persistent backward on
                              # the grid that leaves CUs to RCCL — and the eager form of the same
-                             ("forcedp_graph", {}, ("--graph", "--force-dp")), ("forcedp_eager", {}, ("--force-dp",))]),
+                             ("forcedp_graph", {}, ("--graph", "--force-dp")), ("forcedp_eager", {}, ("--force-dp",)),
+                             # the captured step with its optimizer launches at the end of the side branch + in a graph of
+                             # their own (round 3) instead of inside the step graph, segment by segment on both streams
+                             ("noinlineadam", {"MMQG_INLINE_ADAM": "0"}, ("--graph",)),
+                             # the projection's weight gradient behind / in front of the decoder's backward loop
+                             ("vocablate", {"MMQG_VOCAB_WGRAD": "late"}, ("--graph",))]),
             ("config5", 128, [("x3off", {"MMQG_GEMM_X3": "0"}, ()), ("nowide", {"MMQG_NO_WIDE": "1"}, ()),
                               ("nowidebwd", {"MMQG_NO_WIDE_BWD": "1"}, ()), ("wideksl1", {"MMQG_WIDE_MAX_KSL": "1"}, ())])):
         ref = run("default", workload, B)
@@ -548,7 +553,7 @@ def test_kernel_families_give_the_same_gradients_at_bench_size(mm, tmp_path):
                 assert int(got["persist_bwd_launches"]) == 0
             elif workload == "config2":
                 assert int(got["persist_bwd_launches"]) > 0, "the persistent backward time loop did not run"
-            if tag.startswith("forcedp"):
+            if tag.startswith("forcedp") or tag in ("noinlineadam", "vocablate"):
                 assert int(got["persist_failures"]) == 0 and int(got["persist_bwd_launches"]) > 0
                 # weights after one Adam step of the whole model (incl. the twice-stepped embedding) vs the
                 # single-GPU captured step: the same update where the gradient is not tiny
