@@ -714,14 +714,14 @@ class BatchedTrainer:
         pair = part == "all" and self.chain_first and bool(self.g_text.persist_ws) and not self.distributed and \
             os.environ.get("MMQG_NO_BWD_PAIR", "0") != "1"
         pair_done = []
-        # Single GPU, captured step: Adam rides inside the step graph, one segment at a time as its gradients become final
-        # and on whichever stream is free — the text encoder's behind its weight gradients on the chain stream (beside the
-        # decoder's weight-gradient group on the other), the decoder's on the chain stream as soon as the other stream has
-        # its last gradient (beside the frame encoder's weight gradients), the small rest behind the join.  Adam is
-        # HBM-bound, the GEMMs beside it are matrix-bound and leave CUs empty (160 and 264 workgroups of one per CU); in a
-        # tail of their own the optimizer launches were 136 us of a 4.0 ms step.
+        # Single GPU, captured step: Adam rides inside the step graph, one segment at a time as its gradients become final,
+        # each beside a weight-gradient GEMM of the other stream — chain: [text encoder's weight gradients] Adam(text
+        # encoder) Adam(embedding, both optimizers); side: [decoder's weight gradients] Adam(decoder) [frame encoder's weight
+        # gradients] Adam(frame encoder).  Adam is HBM-bound, the GEMMs beside it are matrix-bound and leave CUs empty (160
+        # and 184 workgroups of one per CU); in a tail of their own the optimizer launches were 136 us of a 4.0 ms step.
+        # (A third stream for the decoder's Adam changes nothing: a replayed graph puts it on the side branch's queue.)
         inline_adam = part == "all" and self._early_adam and self._inline_adam_ok()
-        dec_done = []
+        dec_done, loop_done = [], []
 
         def enc_side(which: str = "both"):   # decoder weight gradients ("s1"), frame encoder backward ("s2")
             s2 = ops._stream()
@@ -735,7 +735,11 @@ class BatchedTrainer:
                 self.g_dec.phase = 0
                 ops.embedding_bwd(w["dxemb_d"].view(-1, E), w["ids_d"], demb)
                 if inline_adam:
-                    dec_done.append(self._mark())     # the decoder segment's gradients are final: its Adam runs on the other stream
+                    # the decoder segment's gradients are final (and this branch's share of the embedding's): its Adam
+                    # here, beside the text encoder's weight-gradient group on the other stream
+                    dec_done.append(self._mark())
+                    torch.cuda.current_stream().wait_event(loop_done[0])        # (the guard word is refreshed behind the last persistent launch)
+                    self._adam("dec")
                 if self.distributed and not torch.cuda.is_current_stream_capturing():
                     # the decoder bucket (everything but the embedding) is final here: start its all-reduce
                     # from the side stream so it runs beside the text encoder's backward
@@ -750,6 +754,8 @@ class BatchedTrainer:
                     check(lib.mmqg_frame_cnn_bwd(C.byref(self.d_cnn), C.byref(self.g_cnn), s2), "frame_cnn_bwd")
                 if self.distributed and not torch.cuda.is_current_stream_capturing():
                     self.reducer.reduce("vid")          # frame encoder gradients are final too
+            if which == "both" and inline_adam:
+                self._adam("vid")
             if which == "both" and self._early_adam and not inline_adam:
                 # (MMQG_INLINE_ADAM=0, the round-3 arrangement) single GPU, captured step: the decoder's and the frame
                 # encoder's gradients are final here, and nothing later in the step reads their parameters — their Adam
@@ -764,6 +770,9 @@ class BatchedTrainer:
             else:
                 self.g_text.phase = 1
                 check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, loop)")
+            if inline_adam:
+                self._adam("guard")         # behind the last persistent launch of the step; every optimizer launch reads it
+                loop_done.append(self._mark())
             self.g_text.phase = 2
             check(lib.mmqg_lstm_seq_bwd(C.byref(self.d_text), C.byref(self.g_text), s), "lstm_seq_bwd(text, wgrad)")
             self.g_text.phase = 0
@@ -781,12 +790,12 @@ class BatchedTrainer:
                 self._adam("begin")
             enc_chain()
             if inline_adam:
-                self._adam("text")          # (behind the last persistent launch of the step: the guard is refreshed here)
+                self._adam("text")
             with self._fork_from(mark):
                 enc_side()
             if inline_adam:
-                torch.cuda.current_stream().wait_event(dec_done[0])
-                self._adam("dec")
+                torch.cuda.current_stream().wait_event(dec_done[0])       # the embedding gradient has a part from either branch
+                self._adam("emb")
             self._join()
             if inline_adam:
                 self._adam("end")
@@ -880,10 +889,10 @@ class BatchedTrainer:
         b1, b2 = self.betas
         scale = 1.0 / self.world
         split = self._adam_split()
-        if part in ("begin", "text", "dec", "end"):
+        if part in ("begin", "guard", "text", "dec", "vid", "emb", "end"):
             # the single-GPU graph step's in-graph optimizer (see _loss_and_backward): 'begin' advances Adam's step
-            # number, 'text' refreshes the guard and updates the text encoder, 'dec' the decoder, 'end' the frame
-            # encoder and the embedding (twice: the reference's two optimizers) and closes the step
+            # number, 'guard' refreshes the guard word, 'text' / 'dec' / 'vid' update the text encoder / decoder / frame
+            # encoder, 'emb' the embedding (twice: the reference's two optimizers), 'end' closes the step
             bk = self.reducer.buckets
             d0, v0, v1 = bk["dec"][0], bk["vid"][0], bk["rest"][0]
             e0, e1 = self.segments["emb"]
@@ -898,15 +907,18 @@ class BatchedTrainer:
                                                  self.lr, b1, b2, self.eps, self.adam_dev.data_ptr(), scale, guard, s), what)
             if part == "begin":
                 check(lib.mmqg_counter_add(self.adam_dev.data_ptr(), 1, s), "counter_add")
-            elif part == "text":
+            elif part == "guard":
                 check(lib.mmqg_persist_guard_refresh(guard, s), "persist_guard_refresh")
+            elif part == "text":
                 upd(v1, e0)
             elif part == "dec":
                 upd(d0, v0)
-            else:
+            elif part == "vid":
                 upd(v0, v1)
+            elif part == "emb":
                 upd(e0, self.n_params)
                 upd(e0, e1, self.emb_m2.data_ptr(), self.emb_v2.data_ptr(), "adam_step(embedding, 2nd optimizer)")
+            else:
                 check(lib.mmqg_counter_add(self.step_dev.data_ptr(), 1, s), "counter_add")
             return
         if part in ("all", "early"):

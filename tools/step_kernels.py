@@ -3,9 +3,9 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-lo, hi = adam[-7] + 1, adam[-5]
-step = rows[lo:hi + 1]
+# (a step starts with the batch repack; the optimizer launches are no marker: their number depends on the arrangement)
+pack = [i for i, r in enumerate(rows) if "pack_batch_kernel" in r["Kernel_Name"]]
+step = rows[pack[-3]:pack[-2]]
 t0 = int(step[0]["Start_Timestamp"])
 for r in step:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
