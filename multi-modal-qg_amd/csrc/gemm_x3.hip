@@ -354,6 +354,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
             x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
         }
     };
+    // (m-major rows as global loads with a 64-bit scalar row base each.  Tried in round 4: the same loads through a buffer
+    // descriptor with the k row as the SCALAR offset — one s_add per load instead of a scalar multiply, a clamp and a 64-bit
+    // vector add, 160 instructions fewer per chunk — ran SLOWER: 2.72-2.82 us per 32-k chunk against 2.32-2.55 for the
+    // weight-gradient layout, the step 4.03 against 3.95 ms; sixteen loads back to back with nothing between them.)
     auto fetch_m = [&](const float* P, int ld, unsigned col_off, int kb, float (&x)[16]) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {

@@ -519,7 +519,7 @@ class BatchedTrainer:
     def _stage_host_batch(self, batch: dict):
         """A batch in HOST memory (what the reference's DataLoader hands over, train.py:144-162) on its way to the device
         without blocking the host between two replays of the step graph: the tensors go into one of two pinned staging
-        sets with ONE plain memcpy each (tensors that already are pinned are read in place), the transfer runs on a
+        sets with ONE plain memcpy each, the transfer runs on a
         second stream — beside the previous step, which the host is a step ahead of — into a device staging set, and the
         compute stream waits for that transfer only.  Returns (device batch, event to record after the pack launch).
         MMQG_HOST_BATCH: ``dma`` (default) = asynchronous copies by the copy engine, which needs no CU and therefore runs
@@ -545,8 +545,12 @@ class BatchedTrainer:
         src, sptr = {}, {}
         for k, dt in self._HOST_KEYS:
             t = batch[k]
-            if t.dtype == dt and t.is_contiguous() and t.is_pinned():
-                src[k], sptr[k] = t, t.data_ptr()        # already pinned (DataLoader(pin_memory=True)): read in place
+            if mode == "mapped" and t.dtype == dt and t.is_contiguous() and t.is_pinned():
+                # already pinned (DataLoader(pin_memory=True)): the kernel reads it in place.  (The copy engine does not:
+                # asynchronous copies straight out of the caller's pinned tensors ran 12 % slower than out of the staging
+                # set at config 1 — 3.94 against 3.48 ms per step, two boxes — and no faster anywhere else; the memcpy
+                # into the staging set is host time beside the previous step.)
+                src[k], sptr[k] = t, t.data_ptr()
             else:
                 h = st["host"][k]
                 if t.dtype == dt and t.is_contiguous():

@@ -625,7 +625,8 @@ def test_persistent_decoder_forward_matches_the_launched_loop(mm, case):
     assert float(got["hs_d"].abs().max()) > 0
 
 
-@pytest.mark.parametrize("case", ["h128_b5_ragged", "h128_b5_masked_skip", "h256_b17_dropout", "config2_b33", "config2_b64_tgt7"])
+@pytest.mark.parametrize("case", ["h128_b5_ragged", "h128_b5_masked_skip", "h256_b17_dropout", "config2_b33", "config2_b64_tgt7",
+                                  "config2_tight_b64"])
 def test_persistent_decoder_backward_matches_the_launched_loop(mm, case):
     """csrc/persist_dec_bwd.hip (round 4): the decoder's BACKWARD time loop as one persistent launch against the same loop
     as five launches per token (the gradient descriptor without its persist_ws), in ONE process on the same trainer and
@@ -646,8 +647,12 @@ def test_persistent_decoder_backward_matches_the_launched_loop(mm, case):
                      hidden=256, layers=3, video_hidden=192, text_max_length=40, av_max_length=12, dropout=0.3)
     else:
         c2 = WORKLOADS["config2"]
+        # (score rows of 488 positions: the score-gradient product is a stage of its own; "tight" = attention widths
+        # 32 / 8, 48 positions: every cell lane of the top layer multiplies its own dS row — the small cases above take that
+        # form too, at 4 and 8 slices; this one at 16)
+        tight = dict(text_max_length=32, av_max_length=8) if "tight" in case else {}
         w = Workload(**{**c2.dict(), "name": case, "batch": 33 if case.endswith("b33") else 64,
-                        "tgt_len": 7 if case.endswith("tgt7") else 4, "vocab": 500})
+                        "tgt_len": 7 if case.endswith("tgt7") else 4, "vocab": 500, **tight})
     vid, text, dec = build_models(w, "cuda", seed=11)
     batch = synthetic_batch(w, seed=23, ragged=True)
     tr = _trainer(mm, vid, text, dec, batch, seed=77, **kw).train()
