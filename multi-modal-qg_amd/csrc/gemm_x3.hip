@@ -387,6 +387,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
 #if defined(MMQG_X3_ABLATE) && (MMQG_X3_ABLATE & 1)
         return;
 #endif
+#ifdef MMQG_X3_PRIO          // (compile-time A/B, tools/x3_probe.hip: priority 1 / 3 for the MFMA phase: k-major operands -1..-4 %, m-major +3 %)
+        __builtin_amdgcn_s_setprio(MMQG_X3_PRIO);
+#endif
         const unsigned char* base = smem + buf * kPBuf;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -409,6 +412,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x3pp_kernel(X3Batch b) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ia[term]][i], bn[ib[term]][j], acc[i][j], 0, 0, 0);
             }
         }
+#ifdef MMQG_X3_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // The two groups run SEPARATE loops (same number of barriers): with one loop and a role branch inside, hipcc's
