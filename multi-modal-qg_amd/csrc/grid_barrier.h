@@ -86,6 +86,31 @@ __device__ __forceinline__ bool init(Ctx& c, XBar* b, u32 n_workgroups, u32 max_
     return ok;
 }
 
+// init() in two halves: a kernel whose prologue is long (tens of KB of weights into LDS) announces itself first and waits
+// for the others afterwards, so the flat barrier turns while the prologue's loads fly.
+__device__ __forceinline__ void init_arrive(Ctx& c, XBar* b, u32 max_spins = kDefaultSpins) {
+    c.b = b;
+    c.x = xcc_id();
+    c.k = 0;
+    c.max_spins = max_spins;
+    if (threadIdx.x == 0) {
+        const u32 seen = add_rlx(&b->census[c.x * kLine], 1u);      // (performed before the flat add: see init())
+        asm volatile("; census add returned" ::"v"(seen) : "memory");
+        add_rlx(&b->flat[0], 1u);
+    }
+}
+__device__ __forceinline__ bool init_wait(Ctx& c, u32 n_workgroups) {
+    XBar* b = c.b;
+    bool ok = true;
+    if (threadIdx.x == 0) ok = spin_until_ge(&b->flat[0], n_workgroups, b->fail, c.max_spins);
+    ok = __syncthreads_and(ok);
+    c.n_x = ld_rlx(&b->census[c.x * kLine]);
+    u32 g = 0;
+    for (int i = 0; i < 8; ++i) g += ld_rlx(&b->census[i * kLine]) ? 1u : 0u;
+    c.n_groups = g;
+    return ok;
+}
+
 // The barrier in two halves, so that work which nobody waits for (stores to buffers that only later kernels
 // read, prefetches) can sit between a workgroup's arrival and its wait.
 //   arrive(): every wave drains its (sc1) stores, the workgroup's lane 0 adds to its XCC's counter; the XCC's

@@ -189,6 +189,8 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
     extern __shared__ __attribute__((aligned(16))) f32x4 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    gb::Ctx bar;
+    gb::init_arrive(bar, a.bar, a.max_spins);     // the census / flat barrier turns while the weights are on their way to the LDS
     const int B = a.B, L = a.L, NL = a.NL, H = a.H;
     const int CPU = H / 4;                       // k-chunks per unit (K = 4H, 16 k per chunk)
     const int NG = H / kColsPerUnit;             // column groups per product
@@ -285,9 +287,9 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_bwd_kernel(BwdArgs a
     }
     const int pb_lane = ((tctl * kRows + br) * 16 + 4 * cq) * 4;       // byte offset inside a (workgroup, segment) partial block
 
-    gb::Ctx bar;
-    bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
-    if (ok) ok = gb::sync(bar);                                       // weights are in LDS; nothing else to publish yet
+    // (announced at kernel entry, before the weights were read; no second barrier: the first diagonal reads nothing that
+    // another workgroup of this launch has written and ends with an arrival of its own)
+    bool ok = gb::init_wait(bar, a.expect_wg);
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     const uint64_t seed = a.drop ? eff_seed(a.seed, a.seed_off) : 0;

@@ -305,6 +305,8 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     unsigned* stamps = reinterpret_cast<unsigned*>(frag + kFragF4);      // [T][kTraceSlots], stamped instantiation only
     if (TRACE) for (int i = tid; i < a.T * kTraceSlots; i += kThreads) stamps[i] = 0u;
     const unsigned t_entry = TRACE ? (unsigned)wall_clock64() : 0u;      // (slot 15 of the first token: kernel entry, before the weights are read)
+    gb::Ctx bar;
+    gb::init_arrive(bar, a.bar, a.max_spins);       // the census / flat barrier turns while the 120 KB of weights are on their way
 
     // my tiles of a layer: late tiles [cg * tpcL, ...) of nlate, ahead tiles [cg * tpcA, ...) of H/16
     const int nL2 = cellwg ? max(0, min(tpcL2, nlate21 - cg * tpcL2)) : 0;
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
     // ---- weights -> LDS in fragment order: tile, chunk c, lane (i = lane & 15: output column of the tile, kq = lane >> 4):
     // the four k = 16 c + 4 kq + {0..3} of the slice, i.e. gate c >> 1, units 32 sl + 16 (c & 1) + 4 kq + {0..3}: one
     // 16-byte load from the k-major copy WT[n][gate * H + unit].  The items of all six blocks form ONE list that is read
-    // eight 16-byte loads per thread at a time, in SOURCE order — 8 consecutive lanes cover the 128 contiguous bytes of a
+    // sixteen 16-byte loads per thread at a time, in SOURCE order — 8 consecutive lanes cover the 128 contiguous bytes of a
     // (column, gate) pair, i.e. whole cache lines — and scattered into the LDS (120 KB per workgroup, 30 MB per launch: a
     // loop of one load + one store per thread and matrix took ~60 us of the launch).
     {
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
         start[0] = 0;
 #pragma unroll
         for (int m = 0; m < 6; ++m) start[m + 1] = start[m] + count[m] * 512;
-        constexpr int kUn = 8;
+        constexpr int kUn = 16;       // (15 items per thread at config 2: one round of loads)
         for (int base = 0; base < start[6]; base += kUn * kThreads) {
             f32x4 v[kUn];
             int dst[kUn];
@@ -421,9 +423,9 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_bwd_kernel(DbArgs
         v_off = vm == 0 ? 0 : (vm == 1 ? a.v.H : a.v.H + a.v.Da);
     }
 
-    gb::Ctx bar;
-    bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
-    if (ok) ok = gb::sync(bar);
+    // (announced before the weights were read; no second barrier: the first stage reads nothing another workgroup of this
+    // launch has written — saved activations only — and ends with an arrival of its own)
+    bool ok = gb::init_wait(bar, a.expect_wg);
     const uint64_t seed = a.drop ? eff_seed(a.seed, a.seed_off) : 0;
     const int64_t BH = (int64_t)B * H;
     bool pend = false;                               // an arrival whose wait is still to come
