@@ -559,7 +559,10 @@ def test_kernel_families_give_the_same_gradients_at_bench_size(mm, tmp_path):
                 # single-GPU captured step: the same update where the gradient is not tiny
                 want_dp, got_dp = kept["graph"]["dp"], got["dp"]
                 big = np.abs(want_dp) > 0.99e-4          # |g| > 100 eps: the update is well conditioned there
-                close(got_dp[big], want_dp[big], tol=2e-3, what=f"{workload} {tag}: Adam update vs the single-GPU graph step")
+                # (floor: the update is read back as p_new - p_old, and one ulp of an embedding entry in [4, 8) is 4.8e-7 —
+                # two runs whose atomics summed a gradient in different orders may round such an entry to neighbouring floats)
+                close(got_dp[big], want_dp[big], tol=2e-3, floor=5e-7,
+                      what=f"{workload} {tag}: Adam update vs the single-GPU graph step")
                 assert float(np.abs(got_dp - want_dp).max()) <= 2.002e-4
             kept[tag] = got
             close(got["loss"], ref["loss"], tol=1e-5, what=f"{workload} {tag}: loss vs default")
