@@ -781,9 +781,12 @@ int gemm_x3_grouped(int a_layout, int b_layout, const GemmProblem* probs, const 
             int split = 1;
             if (tiles_total < slots) {
                 // as many slices as fit ONE round of workgroups (a partly filled second round costs a whole one), at most
-                // 8: every slice adds its 256 x 128 partial tile with f32 atomics (tools/x3_split.py: the 1280 x 512 x
-                // 10000 data gradient takes 127 us at 8 slices, 143 at 13, 205 at 4)
-                static const int max_split = [] { const char* e = getenv("MMQG_X3_MAX_SPLIT"); return e && atoi(e) > 0 ? atoi(e) : 8; }();
+                // 4: every slice adds its 256 x 128 partial tile with f32 atomics.  Alone, a thin product likes more (tools/
+                // x3_split.py: the 1280 x 512 x 10000 data gradient takes 127 us at 8 slices, 143 at 13, 205 at 4); in the
+                // step, where a second queue has a product of its own for the CUs a launch leaves free, fewer and longer
+                // slices win: 3.870 / 3.883 / 3.895 ms per step at 4 against 3.907 / 3.911 / 3.899 at 8 (3.95 at 3, 4.11 at 2;
+                // MMQG_X3_MAX_SPLIT overrides)
+                static const int max_split = [] { const char* e = getenv("MMQG_X3_MAX_SPLIT"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
                 split = (int)std::min<int64_t>(std::max<int64_t>(slots / tiles_total, 1), max_split);
                 split = std::min(split, std::max(1, nch / 8));
             }
