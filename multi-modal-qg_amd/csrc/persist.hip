@@ -173,24 +173,6 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_fwd_kernel(PersistAr
     f32x4* scratch = lds + wtotal;                // [task][wave][lane] partial tiles of the k-split waves
     if (tid < 64) lds[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- weights -> LDS, fragment order: chunk c (16 k), lane l = (i = l & 15: gate column (unit i>>2, gate i&3),
-    // kq = l >> 4): the 4 consecutive k = 16c + 4kq + {0..3} of that weight row
-#pragma unroll
-    for (int ti = 0; ti < kMaxTasks; ++ti) {
-        const TaskInfo& t = tk[ti];
-        const int n = t.nch * 64;
-        for (int idx = tid; idx < n; idx += kThreads) {
-            const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
-            const int row = (i & 3) * H + 4 * t.unit + (i >> 2);
-            const int k = 16 * c + 4 * kq;
-            const float* src;
-            if (t.layer == 0) src = a.w_hh[0] + (int64_t)row * H + k;
-            else if (k < H) src = pick(a.w_ih, t.layer) + (int64_t)row * H + k;
-            else src = pick(a.w_hh, t.layer) + (int64_t)row * H + (k - H);
-            lds[t.woff + idx] = *reinterpret_cast<const f32x4*>(src);
-        }
-    }
-
     // exchange buffers: hx [L][2][slot] directly followed by xd [L-1][2][slot], one descriptor over both
     // (sc1 loads / stores carry aux = 16)
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.hx, 0, (2 * L - 1) * 2 * slot_f * 4, 0x00020000);
@@ -236,9 +218,33 @@ __global__ __launch_bounds__(kThreads, 2) void lstm_persist_fwd_kernel(PersistAr
                                               (((t.layer * 2 + 1) * slot_f) + (t.unit * kRows + b) * 4 + q) * 4, 0, 16);
     }
 
+    // h(-1) is on its way: once every wave's stores are acknowledged the launch announces itself at the flat start-up barrier,
+    // which turns while the weights are read — when it has turned, every workgroup's h(-1) is published, so no second
+    // barrier is needed before the first diagonal
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     gb::Ctx bar;
-    bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
-    if (ok) ok = gb::sync(bar);                   // weights are in LDS (workgroup-local), h(-1) is published
+    gb::init_arrive(bar, a.bar, a.max_spins);
+
+    // ---- weights -> LDS, fragment order: chunk c (16 k), lane l = (i = l & 15: gate column (unit i>>2, gate i&3),
+    // kq = l >> 4): the 4 consecutive k = 16c + 4kq + {0..3} of that weight row
+#pragma unroll
+    for (int ti = 0; ti < kMaxTasks; ++ti) {
+        const TaskInfo& t = tk[ti];
+        const int n = t.nch * 64;
+        for (int idx = tid; idx < n; idx += kThreads) {
+            const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
+            const int row = (i & 3) * H + 4 * t.unit + (i >> 2);
+            const int k = 16 * c + 4 * kq;
+            const float* src;
+            if (t.layer == 0) src = a.w_hh[0] + (int64_t)row * H + k;
+            else if (k < H) src = pick(a.w_ih, t.layer) + (int64_t)row * H + k;
+            else src = pick(a.w_hh, t.layer) + (int64_t)row * H + (k - H);
+            lds[t.woff + idx] = *reinterpret_cast<const f32x4*>(src);
+        }
+    }
+
+    bool ok = gb::init_wait(bar, a.expect_wg);        // (its workgroup barrier also closes the weight fill)
     // the second-dispatched half of an 8-wave workgroup loses the issue arbitration on every SIMD to its older partner
     // (MI355X_MICROARCH.md, two waves per SIMD, item 4): one static priority for waves 4-7 evens the two halves out
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);

@@ -178,35 +178,6 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
     f32x4* att_comb = reinterpret_cast<f32x4*>(att_e + 7 * kMaxSeg); // [6][16] partial contexts of the later waves of split items
     if (tid < 64) lds[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- weights -> LDS in fragment order: chunk c, lane (i = lane & 15: output column, kq = lane >> 4): 4 consecutive k
-    // of that output column's weight row.  Gate column i of a unit: weight row (i & 3) * H + 4 * unit + (i >> 2).
-    if (wg_l0) {
-        for (int idx = tid; idx < nch0 * 64; idx += kThreads) {
-            const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
-            const int row = (i & 3) * H + 4 * unit + (i >> 2), k = 16 * c + 4 * kq;
-            const float* src = k < Cw ? a.w_ih0c + (int64_t)row * a.ld_w0 + k : a.w_hh0 + (int64_t)row * H + (k - Cw);
-            lds[wb0 + idx] = *reinterpret_cast<const f32x4*>(src);
-        }
-    }
-    if (wg_l12) {
-        for (int idx = tid; idx < 2 * nch12 * 64; idx += kThreads) {
-            const int which = idx >= nch12 * 64, id2 = idx - which * nch12 * 64;
-            const int c = id2 >> 6, l = id2 & 63, i = l & 15, kq = l >> 4;
-            const int row = (i & 3) * H + 4 * unit + (i >> 2), k = 16 * c + 4 * kq;
-            const float* wi = which ? a.w_ih2 : a.w_ih1;
-            const float* wh = which ? a.w_hh2 : a.w_hh1;
-            const float* src = k < H ? wi + (int64_t)row * H + k : wh + (int64_t)row * H + (k - H);
-            lds[(which ? wb1 : wb0) + id2] = *reinterpret_cast<const f32x4*>(src);
-        }
-    }
-    if (wg_s) {
-        for (int idx = tid; idx < nchs * 64; idx += kThreads) {
-            const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
-            const int srow = min(16 * s_tile + i, a.S - 1);
-            lds[wbs + idx] = *reinterpret_cast<const f32x4*>(a.w_attn_h + (int64_t)srow * a.ld_wa + 16 * c + 4 * kq);
-        }
-    }
-
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.hx, 0, a.ex_bytes, 0x00020000);
 
     // ---- layer-phase roles: wave = (row block mb = wave & 3, k half ks = wave >> 2); the ks == 1 wave of a row block
@@ -241,6 +212,43 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hA : 0.f), rs, hoff(lA, -1) + ((unit * kRows + row) * 4 + q) * 4, 0, 16);
         if (wg_l12)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(row < B ? hB : 0.f), rs, hoff(2, -1) + ((unit * kRows + row) * 4 + q) * 4, 0, 16);
+    }
+
+    // h(-1) is on its way: once every wave's stores are acknowledged the launch announces itself at the flat start-up barrier,
+    // which turns while the weights are read — when it has turned, every workgroup's h(-1) is published, so no second
+    // barrier is needed before the first token
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gb::Ctx bar;
+    gb::init_arrive(bar, a.bar, a.max_spins);
+
+    // ---- weights -> LDS in fragment order: chunk c, lane (i = lane & 15: output column, kq = lane >> 4): 4 consecutive k
+    // of that output column's weight row.  Gate column i of a unit: weight row (i & 3) * H + 4 * unit + (i >> 2).
+    if (wg_l0) {
+        for (int idx = tid; idx < nch0 * 64; idx += kThreads) {
+            const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
+            const int row = (i & 3) * H + 4 * unit + (i >> 2), k = 16 * c + 4 * kq;
+            const float* src = k < Cw ? a.w_ih0c + (int64_t)row * a.ld_w0 + k : a.w_hh0 + (int64_t)row * H + (k - Cw);
+            lds[wb0 + idx] = *reinterpret_cast<const f32x4*>(src);
+        }
+    }
+    if (wg_l12) {
+        for (int idx = tid; idx < 2 * nch12 * 64; idx += kThreads) {
+            const int which = idx >= nch12 * 64, id2 = idx - which * nch12 * 64;
+            const int c = id2 >> 6, l = id2 & 63, i = l & 15, kq = l >> 4;
+            const int row = (i & 3) * H + 4 * unit + (i >> 2), k = 16 * c + 4 * kq;
+            const float* wi = which ? a.w_ih2 : a.w_ih1;
+            const float* wh = which ? a.w_hh2 : a.w_hh1;
+            const float* src = k < H ? wi + (int64_t)row * H + k : wh + (int64_t)row * H + (k - H);
+            lds[(which ? wb1 : wb0) + id2] = *reinterpret_cast<const f32x4*>(src);
+        }
+    }
+    if (wg_s) {
+        for (int idx = tid; idx < nchs * 64; idx += kThreads) {
+            const int c = idx >> 6, l = idx & 63, i = l & 15, kq = l >> 4;
+            const int srow = min(16 * s_tile + i, a.S - 1);
+            lds[wbs + idx] = *reinterpret_cast<const f32x4*>(a.w_attn_h + (int64_t)srow * a.ld_wa + 16 * c + 4 * kq);
+        }
     }
 
     // ---- attention-phase roles: waves 1-4 = two text items (two waves each: rows halved; ONE item over all four waves when the batch
@@ -279,9 +287,7 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
         else { for (int k = 0; k < 2; ++k) if (g + k * a.G < nv) need_rb |= 1u << (((g + k * a.G) / chunks_v) >> 4); }
         if (g < na) need_rb |= 1u << ((g / chunks_a) >> 4);
     }
-    gb::Ctx bar;
-    bool ok = gb::init(bar, a.bar, a.expect_wg, a.max_spins);
-    if (ok) ok = gb::sync(bar);
+    bool ok = gb::init_wait(bar, a.expect_wg);        // (its workgroup barrier also closes the weight fill)
     f32x4 aheadA = f32x4{0.f, 0.f, 0.f, 0.f}, aheadB = aheadA;
     if (ok && wg_l0 && cellw)          // token 0 of layer 0: h_0(-1) W_hh0^T
         aheadA = wave_product<kRingAhead>(rs, make_prod(H / 16, 0, 1, hoff(0, -1), wb0 + (Cw / 16) * 64, lane_off), lds, lane);
