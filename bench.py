@@ -611,6 +611,11 @@ def main(argv=None):
         dt = float(t)
     if not (loss_val == loss_val):
         raise SystemExit("loss is NaN")
+    tr.check_health(sync=True)              # a persistent launch of the LAST step that timed out at its barrier raises here
+    from mmqg_amd import _lib as _mlib
+    _l = _mlib.load()
+    health = {"persistent_launch_failures": int(_l.mmqg_persist_failures()),
+              "persistent_launches_declined": int(_l.mmqg_persist_declined_count())}
 
     out = {"metric": "training questions/sec (fwd+bwd+optimizer)", "value": round(world * B * a.steps / dt, 2),
            "unit": "questions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -626,7 +631,7 @@ def main(argv=None):
                       "skip_zero_value_rows": bool(a.skip_zero_rows),
                       "world_size": torch.distributed.get_world_size() if use_pg else 1,
                       "collective_backend": backend},
-           "final_loss": round(loss_val, 4)}
+           "final_loss": round(loss_val, 4), "health": health}
     if use_pg:
         out["config"]["allreduce_ms"] = allreduce_times(tr)
     if rank == 0:
