@@ -380,12 +380,26 @@ __global__ __launch_bounds__(kThreads, 2) void decoder_persist_fwd_kernel(DecArg
             if (it_mod >= 0) {
                 const bool masked = a.v.mask_mode == MMQG_MASK_INTENDED;
                 // softmax of the whole segment (both halves of a split item do it)
+                // (the segment's scores — up to kMaxSeg / 64 = 5 per lane — all asked for before the first is used: as a loop of
+                // one load per trip this was five L2 round trips in a row right behind the score barrier, 3 us of the
+                // attention window)
                 float lmax = -INFINITY;
-                for (int i = lane; i < L; i += 64) {
-                    float s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, sxoff(t) + (it_b * a.ldS + seg_off + i) * 4, 0, 0));
-                    if (masked && i >= valid) s = -INFINITY;
-                    e[i] = s;
-                    lmax = fmaxf(lmax, s);
+                {
+                    constexpr int NI = kMaxSeg / 64;
+                    float sv[NI];
+                    const int sbase = sxoff(t) + (it_b * a.ldS + seg_off) * 4;
+#pragma unroll
+                    for (int u = 0; u < NI; ++u)
+                        sv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, sbase + min(lane + 64 * u, L - 1) * 4, 0, 0));
+#pragma unroll
+                    for (int u = 0; u < NI; ++u) {
+                        const int i = lane + 64 * u;
+                        if (i < L) {
+                            const float s = (masked && i >= valid) ? -INFINITY : sv[u];
+                            e[i] = s;
+                            lmax = fmaxf(lmax, s);
+                        }
+                    }
                 }
                 lmax = wave_max(lmax);
                 float lsum = 0.f;
