@@ -611,7 +611,7 @@ class BatchedTrainer:
         self._side.wait_event(ev)
         return torch.cuda.stream(self._side)
 
-    def _forward(self, training: bool, zero_grads: bool = False):
+    def _forward(self, training: bool):
         lib, w = _lib.load(), self.ws
         L, B, H, V = self.L, self.B, self.H, self.V
         for d in (self.d_vid, self.d_text, self.d_dec):
@@ -632,11 +632,6 @@ class BatchedTrainer:
 
         def side_branch():
             s = ops._stream()
-            if zero_grads:
-                # (captured step: the gradient buffer is cleared at the head of THIS branch, which has 400 us of slack before
-                # the decoder's loop joins it, instead of 15 us in front of the text encoder on the dependent chain; the
-                # first accumulation into it is the backward's, behind the join)
-                self.flat_g.zero_()
             if self._cnn_on:
                 self.d_cnn.training = int(training)
                 check(lib.mmqg_frame_cnn_fwd(C.byref(self.d_cnn), s), "frame_cnn_fwd")
@@ -1004,11 +999,11 @@ class BatchedTrainer:
     # ------------------------------------------------------------------------ hipGraph
     def _graph_body(self, part: str = "all"):
         if part in ("all", "dec"):
-            if self._serial or not self.chain_first:
-                self.flat_g.zero_()
-                self._forward(True)
-            else:
-                self._forward(True, zero_grads=True)
+            # (clearing the gradient buffer at the head of the side branch instead — 15 us off this chain — was tried in round 4:
+            # the frame encoder's chain on that branch then loses its race with the text encoder's persistent launch, its last
+            # two steps run behind it and the decoder's loop starts no earlier: `git show c4142df`)
+            self.flat_g.zero_()
+            self._forward(True)
         self._loss_and_backward(part)
 
     def _graph_step(self, batch):
