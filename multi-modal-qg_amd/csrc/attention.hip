@@ -366,20 +366,34 @@ __global__ __launch_bounds__(256) void attn_dvalues_kernel(DValK a) {
         for (int r = 0; r < kDvRows; ++r)
 #pragma unroll
             for (int k = 0; k < W; ++k) acc[r][k] = 0.f;
-        for (int t = 0; t < a.T; ++t) {
-            const float* src = a.dctx + t * a.dctx_stride_t + (int64_t)b * a.ld_c + a.ctx_off + c * W;
-            float x[W];
-            if constexpr (W == 4) {
-                const float4 q = *reinterpret_cast<const float4*>(src);
-                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
-            } else {
-                x[0] = src[0];
+        // eight tokens' context gradients in flight at a time (as a loop of one load per token every load was waited for
+        // where it was issued: T dependent round trips for a kernel that is 12 us long at T = 20)
+        constexpr int kTU = 8;
+        const float* src0 = a.dctx + (int64_t)b * a.ld_c + a.ctx_off + c * W;
+        for (int t0 = 0; t0 < a.T; t0 += kTU) {
+            float x[kTU][W];
+#pragma unroll
+            for (int u = 0; u < kTU; ++u) {
+                const float* src = src0 + (int64_t)min(t0 + u, a.T - 1) * a.dctx_stride_t;
+                if constexpr (W == 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(src);
+                    x[u][0] = q.x; x[u][1] = q.y; x[u][2] = q.z; x[u][3] = q.w;
+                } else {
+                    x[u][0] = src[0];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < kDvRows; ++r) {
-                const float wv = aw[t * kDvRows + r];
+            for (int u = 0; u < kTU; ++u) {
+                const int t = t0 + u;
+                if (t < a.T) {
 #pragma unroll
-                for (int k = 0; k < W; ++k) acc[r][k] += wv * x[k];
+                    for (int r = 0; r < kDvRows; ++r) {
+                        const float wv = aw[t * kDvRows + r];
+#pragma unroll
+                        for (int k = 0; k < W; ++k) acc[r][k] += wv * x[u][k];
+                    }
+                }
             }
         }
 #pragma unroll

@@ -664,12 +664,22 @@ __global__ __launch_bounds__(256, 2) void wide_bwd_kernel(SkinnyBatch batch) {
         for (int sl = 0; sl < 4; ++sl) {
             const int o = (min(sl, ksl - 1) * kRec + row * kBwCols + c8) * 4;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                vp[sl][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16 * h, 0, 16));
-                vm[sl][h] = any_masked ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o + kBwRows * kBwCols * 4 + 16 * h, 0, 16))
-                                       : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int h = 0; h < 2; ++h) vp[sl][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16 * h, 0, 16));
         }
+        if (any_masked) {                      // (uniform)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int o = (min(sl, ksl - 1) * kRec + row * kBwCols + c8) * 4 + kBwRows * kBwCols * 4;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) vm[sl][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16 * h, 0, 16));
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) { vm[sl][0] = f32x4{0.f, 0.f, 0.f, 0.f}; vm[sl][1] = vm[sl][0]; }
+        }
+        // (every slice's tile in flight before the first is added: left alone the scheduler pairs each of the up to 16 loads —
+        // cross-XCD, write-through data: a fabric round trip each — with its add, load, s_waitcnt vmcnt(0), add)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) { sp[h] = f32x4{0.f, 0.f, 0.f, 0.f}; sm[h] = sp[h]; }
 #pragma unroll
