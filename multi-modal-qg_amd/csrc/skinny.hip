@@ -368,66 +368,56 @@ __global__ __launch_bounds__(64 * NW, 1) void cell_fwd_wide_kernel(SkinnyBatch b
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) Bp[cc] = a.p[pi].B + (int64_t)nb[cc] * a.p[pi].ldb;
         const int K = a.p[pi].K;
-        constexpr int U = 2;                  // k-chunks per step: the NEXT step's 12 sixteen-byte loads are in flight behind
-                                              // the current step's 64 MFMAs (branch-free loop: clamped addresses, chunks
-                                              // past the range zeroed after the load)
-        float4 av[4][U], bv[2][U], an[4][U], bn[2][U];
-        auto fetch = [&](float4 (&fa)[4][U], float4 (&fb)[2][U], int q) {
+        // One k-chunk (32 MFMAs) per step, SIX operand sets taking turns (no register copies; one wave per SIMD: 512
+        // registers): the loads of the next five steps are in flight behind a step's MFMAs (see wide_bwd_kernel).
+        // Branch-free: clamped addresses, chunks past the range zeroed after the load.
+        constexpr int NB = 6;
+        float4 fa[NB][4], fb[NB][2];
+        auto fetch = [&](float4 (&xa)[4], float4 (&xb)[2], int q) {
+            const int k = max(min((min(q, hi - 1) - pbeg) * 16 + 4 * ls, K - 4), 0);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = max(min((q + u - pbeg) * 16 + 4 * ls, K - 4), 0);
+            for (int r = 0; r < 4; ++r) xa[r] = *reinterpret_cast<const float4*>(Ap[r] + k);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) fa[r][u] = *reinterpret_cast<const float4*>(Ap[r] + k);
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) fb[cc][u] = *reinterpret_cast<const float4*>(Bp[cc] + k);
-            }
+            for (int cc = 0; cc < 2; ++cc) xb[cc] = *reinterpret_cast<const float4*>(Bp[cc] + k);
         };
-        fetch(av, bv, lo);
-        for (int q = lo; q < hi; q += U) {
-            fetch(an, bn, min(q + U, hi - 1));
+        auto step = [&](float4 (&av)[4], float4 (&bv)[2], int q) {
+            if (!((q - pbeg) * 16 + 4 * ls < K)) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool in = q + u < hi && (q + u - pbeg) * 16 + 4 * ls < K;
-                if (!in) {
+                for (int r = 0; r < 4; ++r) av[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) av[r][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) bv[cc][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                for (int cc = 0; cc < 2; ++cc) bv[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int r = 0; r < 4; ++r) {
+                av[r].x = __shfl(av[r].x, src_lane, 64); av[r].y = __shfl(av[r].y, src_lane, 64);
+                av[r].z = __shfl(av[r].z, src_lane, 64); av[r].w = __shfl(av[r].w, src_lane, 64);
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    av[r][u].x = __shfl(av[r][u].x, src_lane, 64); av[r][u].y = __shfl(av[r][u].y, src_lane, 64);
-                    av[r][u].z = __shfl(av[r][u].z, src_lane, 64); av[r][u].w = __shfl(av[r][u].w, src_lane, 64);
-                }
+            for (int cc = 0; cc < 2; ++cc) {
+                bv[cc].x = __shfl(bv[cc].x, src_lane, 64); bv[cc].y = __shfl(bv[cc].y, src_lane, 64);
+                bv[cc].z = __shfl(bv[cc].z, src_lane, 64); bv[cc].w = __shfl(bv[cc].w, src_lane, 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    bv[cc][u].x = __shfl(bv[cc][u].x, src_lane, 64); bv[cc][u].y = __shfl(bv[cc][u].y, src_lane, 64);
-                    bv[cc][u].z = __shfl(bv[cc][u].z, src_lane, 64); bv[cc][u].w = __shfl(bv[cc][u].w, src_lane, 64);
+                    acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].x, bv[cc].x, acc[r][cc], 0, 0, 0);
+                    acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].y, bv[cc].y, acc[r][cc], 0, 0, 0);
+                    acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].z, bv[cc].z, acc[r][cc], 0, 0, 0);
+                    acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r].w, bv[cc].w, acc[r][cc], 0, 0, 0);
                 }
-            }
             __builtin_amdgcn_sched_barrier(0);
+        };
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+        for (int sx = 0; sx < NB - 1; ++sx) fetch(fa[sx], fb[sx], lo + sx);
+        for (int q = lo; q < hi; q += NB) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].x, bv[cc][u].x, acc[r][cc], 0, 0, 0);
-                        acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].y, bv[cc][u].y, acc[r][cc], 0, 0, 0);
-                        acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].z, bv[cc][u].z, acc[r][cc], 0, 0, 0);
-                        acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][u].w, bv[cc][u].w, acc[r][cc], 0, 0, 0);
-                    }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) av[r][u] = an[r][u];
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) bv[cc][u] = bn[cc][u];
+            for (int sx = 0; sx < NB; ++sx) {
+                if (q + sx >= hi) break;                                                 // (uniform)
+                fetch(fa[(sx + NB - 1) % NB], fb[(sx + NB - 1) % NB], q + sx + NB - 1);      // the set the previous step freed
+                step(fa[sx], fb[sx], q + sx);
             }
         }
     }
