@@ -368,10 +368,10 @@ __global__ __launch_bounds__(64 * NW, 1) void cell_fwd_wide_kernel(SkinnyBatch b
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) Bp[cc] = a.p[pi].B + (int64_t)nb[cc] * a.p[pi].ldb;
         const int K = a.p[pi].K;
-        // One k-chunk (32 MFMAs) per step, SIX operand sets taking turns (no register copies; one wave per SIMD: 512
-        // registers): the loads of the next five steps are in flight behind a step's MFMAs (see wide_bwd_kernel).
-        // Branch-free: clamped addresses, chunks past the range zeroed after the load.
-        constexpr int NB = 6;
+        // One k-chunk (32 MFMAs) per step, THREE operand sets taking turns (no register copies; see wide_bwd_kernel).  Config 5,
+        // same box, ms per step: two sets of two chunks with copies 21.00, 3 sets 20.64-20.71, 4 sets 20.59-20.80, 6 sets
+        // 20.81-20.90, 8 sets 21.55.  Branch-free: clamped addresses, chunks past the range zeroed after the load.
+        constexpr int NB = 3;
         float4 fa[NB][4], fb[NB][2];
         auto fetch = [&](float4 (&xa)[4], float4 (&xb)[2], int q) {
             const int k = max(min((min(q, hi - 1) - pbeg) * 16 + 4 * ls, K - 4), 0);
@@ -528,12 +528,13 @@ __global__ __launch_bounds__(256, 2) void wide_bwd_kernel(SkinnyBatch batch) {
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) Bp[cc] = a.p[pi].B + (int64_t)nb[cc] * a.p[pi].ldb;
         const int K = a.p[pi].K;
-        // One k-chunk (32 MFMAs) per step, FIVE operand sets taking turns (no register copies): the 6 sixteen-byte loads of
-        // each of the next FOUR steps are in flight behind a step's MFMAs, 4 x 32 x 32 = 4,096 cycles of cover.  With two
-        // sets of two chunks (one step = 2,048 cycles ahead) a weight chunk that came from the Infinity Cache — a layer-step
-        // streams 33 MB of weights, three layers do not stay in the L2s — arrived after the MFMAs that were to hide it.
-        // No branch around a load: addresses are clamped and out-of-range chunks are zeroed after the load.
-        constexpr int NB = 5;
+        // One k-chunk (32 MFMAs) per step, THREE operand sets taking turns (no register copies): the 6 sixteen-byte loads of
+        // each of the next two steps are in flight behind a step's MFMAs.  Before: two sets of two chunks, 64 MFMAs per
+        // step and 24 v_mov per step to hand the next set over.  Deeper rotations lost again (config 5, same box, ms per
+        // step: 3 sets 20.51-20.53, 4 sets 20.52-20.54, 5 sets 20.59-20.61): what pays is the finer step without the
+        // copies, not the depth.  No branch around a load: addresses are clamped and out-of-range chunks are zeroed after
+        // the load.
+        constexpr int NB = 3;
         float4 fa[NB][4], fb[NB][2];
         auto fetch = [&](float4 (&xa)[4], float4 (&xb)[2], int q) {
             const int k = min((min(q, hi - 1) - pbeg) * 16 + 4 * ls, K - 4);
